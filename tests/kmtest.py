@@ -1,0 +1,135 @@
+"""Shared helpers for the test-suite: ctypes bindings of the oracle and of the product C-ABI library,
+golden-fixture access, and CSR <-> triple conversion.  Test infrastructure only."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+INP = os.path.join(GOLD, "inputs")
+ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "libkmers_oracle.so")
+PRODUCT_SO = os.path.join(ROOT, "kmers_amd", "lib", "libkmers.so")
+
+X_ARGS = [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64),
+          C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+Y_ARGS = [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int)]
+
+
+def cfiles(paths):
+    arr = (C.c_char_p * len(paths))()
+    arr[:] = [p.encode() for p in paths]
+    return arr
+
+
+class Lib:
+    """Uniform view of a library exporting the six reference symbols under an optional prefix."""
+
+    def __init__(self, path, prefix=""):
+        self.lib = C.CDLL(path)
+        self.prefix = prefix
+        for name in ("fasta_to_kmers_csr", "fasta_to_kmers_csr_cat_subseq"):
+            f = getattr(self.lib, prefix + name)
+            f.restype = C.c_int
+            f.argtypes = X_ARGS
+        for name in ("fasta_count_kmers", "fastq_gz_count_kmers"):
+            f = getattr(self.lib, prefix + name)
+            f.restype = C.c_int
+            f.argtypes = Y_ARGS
+        f = getattr(self.lib, prefix + "kmer_to_id")
+        f.restype = C.c_uint32
+        f.argtypes = [C.c_char_p, C.c_int]
+        f = getattr(self.lib, prefix + "valid_kmer")
+        f.restype = C.c_bool
+        f.argtypes = [C.c_char_p, C.c_int]
+
+    def fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def x(self, paths, K, L=0, cat=False, max_nz=None):
+        """-> (rc, data[:nnz], row_ind, col_ind[:nnz], n_cols)"""
+        M = 4 ** K
+        if max_nz is None:
+            max_nz = sum(os.stat(p).st_size for p in paths if os.path.isfile(p)) + 16
+        data = np.zeros(max_nz, np.float32)
+        col = np.zeros(max_nz, np.uint64)
+        row = np.zeros(M + 1, np.uint64)
+        nnz = C.c_uint64(0)
+        ncols = C.c_int(0)
+        fn = self.fn("fasta_to_kmers_csr_cat_subseq" if cat else "fasta_to_kmers_csr")
+        rc = fn(len(paths), cfiles(paths), K, L, data.ctypes.data_as(C.POINTER(C.c_float)),
+                row.ctypes.data_as(C.POINTER(C.c_uint64)), col.ctypes.data_as(C.POINTER(C.c_uint64)), max_nz,
+                C.byref(nnz), C.byref(ncols))
+        n = nnz.value
+        return rc, data[:n], row, col[:n], ncols.value
+
+    def y(self, paths, K, fastq=False, into=None):
+        M = 4 ** K
+        y = np.zeros(M, np.int32) if into is None else into
+        fn = self.fn("fastq_gz_count_kmers" if fastq else "fasta_count_kmers")
+        rc = fn(len(paths), cfiles(paths), K, y.ctypes.data_as(C.POINTER(C.c_int)))
+        return rc, y
+
+
+def load_oracle():
+    if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
+            os.path.join(ROOT, "oracle", "kmers_oracle.c")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], stdout=subprocess.DEVNULL)
+    return Lib(ORACLE_SO, "oracle_")
+
+
+def load_product():
+    if not os.path.exists(PRODUCT_SO):
+        raise RuntimeError(f"{PRODUCT_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    return Lib(PRODUCT_SO, "")
+
+
+def manifest():
+    with open(os.path.join(GOLD, "manifest.json")) as f:
+        return json.load(f)
+
+
+def case_paths(case):
+    return [os.path.join(INP, f) for f in case["files"]]
+
+
+def golden(case):
+    return np.load(os.path.join(GOLD, case["name"] + ".npz"))
+
+
+def csr_rows(row_ind):
+    """Expand a CSR row pointer to one row id per stored entry (uint32)."""
+    cnt = np.diff(row_ind)
+    nzr = np.flatnonzero(cnt)
+    return np.repeat(nzr.astype(np.uint32), cnt[nzr].astype(np.int64))
+
+
+def assert_x_equal_golden(case, rc, data, row_ind, col_ind, n_cols):
+    g = golden(case)
+    assert rc == 0
+    assert n_cols == int(g["n_cols"])
+    assert data.shape[0] == int(g["nnz"])
+    assert int(row_ind[0]) == 0 and int(row_ind[-1]) == int(g["nnz"])
+    assert np.array_equal(csr_rows(row_ind), g["rows"])
+    assert np.array_equal(col_ind.astype(np.uint32), g["cols"])
+    # float32 values must be bit-identical
+    assert np.array_equal(data.view(np.uint32), g["data"].view(np.uint32))
+
+
+def assert_y_equal_golden(case, rc, y):
+    g = golden(case)
+    assert rc == 0
+    idx = np.flatnonzero(y).astype(np.uint32)
+    assert np.array_equal(idx, g["idx"])
+    assert np.array_equal(y[idx], g["cnt"])
+
+
+def assert_x_equal(a, b):
+    """a, b: (rc, data, row_ind, col_ind, n_cols) tuples from Lib.x"""
+    assert a[0] == b[0]
+    assert a[4] == b[4]
+    assert np.array_equal(a[2], b[2])
+    assert np.array_equal(a[3], b[3])
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
