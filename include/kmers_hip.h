@@ -1,0 +1,122 @@
+/*
+ * kmers_hip.h -- the extended C ABI of libkmers.so: the stages that sit behind the six drop-in calls of
+ * libkmers.h, exposed so that callers can keep data resident in HBM (bench.py, the multi-GPU layer in
+ * kmers_amd/distributed.py, pipelines that feed X straight into a device-side solver).
+ *
+ * Plain pointers and sizes only.  "d_" pointers are device (HBM) addresses on the current HIP device;
+ * everything else is host memory.  `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *
+ *   host ingest   kmers_store_*      FASTA / FASTQ(.gz) -> 2-bit packed bases + validity mask + record table
+ *                                    (replaces the reference's serial parser, src/libkmers.cpp:240-318, and
+ *                                    the record filtering / numbering of :360-371, :398-421, :444-457)
+ *   device y      kmers_hip_count_y  packed store -> dense int32 histogram   (replaces count_kmers :320-328)
+ *   device X      kmers_hip_build_x  packed store -> CSR (data,row_ind,col_ind)
+ *                                    (replaces collect_kmers/fill_indices_coo :218-238 and to_csr :77-169)
+ */
+#ifndef KMERS_HIP_H
+#define KMERS_HIP_H
+
+#include "libkmers.h"
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes beyond the reference's 0 / -1 / -2 ---- */
+#define KMERS_OK 0
+#define KMERS_ERR_OPEN (-1)          /* FASTA file could not be opened (reference code)            */
+#define KMERS_ERR_MAX_NZ (-2)        /* nnz > max_size (reference wrapper's reserved code)         */
+#define KMERS_ERR_NO_DEVICE (-10)    /* no usable HIP device: this library has no CPU fallback     */
+#define KMERS_ERR_HIP (-11)          /* a HIP runtime call failed (message on stderr)              */
+#define KMERS_ERR_BAD_ARG (-12)      /* K outside 1..16, null pointer, bad mode/shard ...          */
+#define KMERS_ERR_TOO_LARGE (-13)    /* more than 2^32-2 sequence positions in one device call     */
+#define KMERS_ERR_WORKSPACE (-14)    /* workspace smaller than kmers_hip_x_workspace_bytes()       */
+#define KMERS_ERR_NOMEM (-15)        /* host allocation failed                                     */
+
+/* ---- host ingest ------------------------------------------------------------------------------- */
+
+/* What the records of a store are (which reference entry point's parsing rules apply). */
+#define KMERS_MODE_X 0        /* fasta_to_kmers_csr:            one record per kept FASTA record (PREDICTED, L) */
+#define KMERS_MODE_X_CAT 1    /* fasta_to_kmers_csr_cat_subseq: one record per file                              */
+#define KMERS_MODE_Y_FASTA 2  /* fasta_count_kmers:             one record per non-PREDICTED FASTA record        */
+#define KMERS_MODE_Y_FASTQ 3  /* fastq_gz_count_kmers:          one record per file (reads joined)               */
+
+/* A packed sequence store in host memory (pinned when a HIP device is present).
+ *
+ * Layout (the same arrays are what the device entry points take):
+ *   position space: record r occupies positions [rec_start[r], rec_start[r+1] - 1) followed by ONE separator
+ *                   position whose validity bit is 0, so no k-mer window can span two records;
+ *                   n_pos = rec_start[n_rec].
+ *   bases[i / 16]   2-bit codes A,C,G,T = 0..3, position i in bits [31-2(i%16) : 30-2(i%16)] (big-endian in
+ *                   the word, so a K-window read as a bit-field IS the reference's k-mer id).  Invalid
+ *                   positions hold code 0.
+ *   valid[i / 32]   bit (i % 32) = 1 iff the byte at position i was one of A,C,G,T.
+ *   rec_start       uint64[n_rec + 1].
+ * Both word arrays are zero-padded with 4 extra words. */
+typedef struct kmers_store kmers_store;
+
+/* Parse `n_files` files under the rules of `mode` with `KMER_NUM_THREADS` host threads (default: all cores,
+ * at most 64) and pack shard `shard` of `n_shards` (contiguous record ranges balanced by positions; pass
+ * 0, 1 for everything).  L is used by the two X modes only.  Returns 0 or KMERS_ERR_OPEN / _BAD_ARG / _NOMEM. */
+int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int shard, int n_shards,
+                       kmers_store **out);
+void kmers_store_free(kmers_store *s);
+
+uint64_t kmers_store_n_pos(const kmers_store *s);         /* positions in this shard (bases + separators)      */
+uint64_t kmers_store_n_rec(const kmers_store *s);         /* records in this shard                             */
+uint64_t kmers_store_n_rec_total(const kmers_store *s);   /* records over all shards (X: the matrix's n_cols)  */
+uint64_t kmers_store_first_rec(const kmers_store *s);     /* global index of this shard's first record         */
+uint64_t kmers_store_n_bases(const kmers_store *s);       /* bases in this shard (n_pos - n_rec)               */
+uint64_t kmers_store_n_windows(const kmers_store *s, int K); /* sum over records of max(len-K+1,0): the metric's k-mers */
+const uint32_t *kmers_store_bases(const kmers_store *s);
+const uint32_t *kmers_store_valid(const kmers_store *s);
+const uint64_t *kmers_store_rec_start(const kmers_store *s);
+size_t kmers_store_bases_words(const kmers_store *s);     /* length of bases[] incl. padding                   */
+size_t kmers_store_valid_words(const kmers_store *s);     /* length of valid[] incl. padding                   */
+
+/* ---- device entry points -------------------------------------------------------------------------- */
+
+/* Number of usable HIP devices (0 when there is none; never fails). */
+int kmers_hip_device_count(void);
+
+/* y: for every position p with valid[p .. p+K) all set, counts[id(p)] += 1.
+ * d_counts is int32[4^K] in HBM and is ADDED to (the caller zeroes it), like the reference's histogram.
+ * Asynchronous on `stream`. */
+int kmers_hip_count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words,
+                      uint64_t n_pos, int K, int32_t *d_counts, void *stream);
+
+/* Bytes of scratch HBM kmers_hip_build_x needs for a store of n_pos positions / n_rec records. */
+size_t kmers_hip_x_workspace_bytes(uint64_t n_pos, uint64_t n_rec, int K);
+
+/* X: CSR of P(k-mer | record) for the store, columns numbered first_col, first_col+1, ...
+ *   d_data f32[max_nz], d_col_ind u64[max_nz], d_row_ind u64[4^K + 1]  (all in HBM, written, not accumulated)
+ *   *nnz_out (host) receives the number of non-zeros.  Returns KMERS_ERR_MAX_NZ (outputs untouched beyond
+ *   row_ind) when nnz > max_nz.  Synchronises `stream` before returning (it has to read nnz back). */
+int kmers_hip_build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words,
+                      const uint64_t *d_rec_start, uint64_t n_pos, uint64_t n_rec, uint64_t first_col, int K,
+                      float *d_data, uint64_t *d_col_ind, uint64_t *d_row_ind, uint64_t max_nz, void *d_workspace,
+                      size_t workspace_bytes, uint64_t *nnz_out, void *stream);
+
+/* ---- per-kernel timing ----------------------------------------------------------------------------------- */
+
+/* While enabled, kmers_hip_build_x brackets every kernel with hipEvents on its launch stream and accumulates the
+ * elapsed time per kernel name (enabling also clears the table).  kmers_hip_profile_get returns entry i:
+ * kernel name, total milliseconds and number of launches.  No counterpart in the reference (its Timer,
+ * src/libkmers.cpp:34-41, prints phase times to stdout). */
+void kmers_hip_profile_enable(int on);
+int kmers_hip_profile_count(void);
+int kmers_hip_profile_get(int i, char *name, size_t name_cap, double *ms_total, uint64_t *calls);
+
+/* ---- host-side merge of per-shard CSRs (multi-GPU X) --------------------------- */
+
+/* Interleave n_parts CSR matrices that cover disjoint ascending column ranges (part g's columns all below
+ * part g+1's) into one CSR: out_row_ind[r] = sum_g row_ind_g[r]; inside a row, part 0's entries first.
+ * All arrays host memory; out_* sized sum(nnz_g) / n_rows+1. */
+int kmers_csr_merge(int n_parts, uint64_t n_rows, const float *const data[], const uint64_t *const row_ind[],
+                    const uint64_t *const col_ind[], float *out_data, uint64_t *out_row_ind, uint64_t *out_col_ind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,550 @@
+// ingest.cpp -- host side of the hot path: FASTA / FASTQ(.gz) -> packed sequence store.
+//
+// Replaces the reference's serial reader and record filtering:
+//   get_next_sequence_fasta ........ reference src/libkmers.cpp:302-318
+//   get_sequence_fastq_gz .......... reference src/libkmers.cpp:240-300
+//   record loops / filters ......... reference src/libkmers.cpp:360-371 (y), :398-421 (cat), :444-457 (X)
+// The reference parses on one thread with getline + tellg/seekg; here a file is mmap'ed, record boundaries
+// are found by all host threads at once, and every record is packed to 2 bits + 1 validity bit per base
+// directly into (pinned) host memory laid out as the kernels read it (include/kmers_hip.h).
+//
+// Line rules kept bit-for-bit (they decide column numbering and k-mer validity):
+//   * the first line of a file is a header whatever it starts with; an empty first line ends the file;
+//   * after that, a header is a line whose first byte is '>';
+//   * a sequence line loses its trailing ' ' bytes only; '\r', tabs, inner blanks stay (as invalid bases);
+//   * a record is skipped when its header contains "PREDICTED"; on the X path also when its length < L
+//     (compared as unsigned in the reference, so a negative L skips everything);
+//   * on the two X paths a sequence ends at its first NUL byte: the reference hands sequence.data() to a
+//     function taking const std::string& (src/libkmers.cpp:233), which re-measures it with strlen.
+#include "kmers_hip.h"
+#include "store.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fcntl.h>
+#include <functional>
+#include <memory>
+#include <string>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <hip/hip_runtime_api.h>
+
+namespace kmers {
+
+int host_threads() {
+    const char *e = getenv("KMER_NUM_THREADS");
+    int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    return n;
+}
+
+void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)> &fn) {
+    if (n == 0) return;
+    if (grain == 0) grain = 1;
+    const size_t n_chunks = (n + grain - 1) / grain;
+    const int nt = (int)std::min<size_t>((size_t)host_threads(), n_chunks);
+    if (nt <= 1) {
+        fn(0, n);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    auto body = [&]() {
+        for (;;) {
+            const size_t c = next.fetch_add(1, std::memory_order_relaxed);
+            if (c >= n_chunks) return;
+            const size_t lo = c * grain;
+            fn(lo, std::min(n, lo + grain));
+        }
+    };
+    std::vector<std::thread> th;
+    th.reserve(nt - 1);
+    for (int i = 1; i < nt; ++i) th.emplace_back(body);
+    body();
+    for (auto &t : th) t.join();
+}
+
+}  // namespace kmers
+
+namespace {
+
+using kmers::parallel_for;
+
+// ---- base code table (reference src/libkmers.cpp:199-211): 0..3 for A,C,G,T, 4 = invalid
+struct CodeTable {
+    uint8_t t[256];
+    CodeTable() {
+        memset(t, 4, sizeof t);
+        t[(uint8_t)'A'] = 0;
+        t[(uint8_t)'C'] = 1;
+        t[(uint8_t)'G'] = 2;
+        t[(uint8_t)'T'] = 3;
+    }
+};
+const CodeTable g_codes;
+
+// ---- a read-only view of a whole file
+struct FileView {
+    const uint8_t *p = nullptr;
+    size_t n = 0;
+    bool ok = false;
+    bool mapped = false;
+    ~FileView() {
+        if (mapped && p) munmap((void *)p, n);
+    }
+    bool open(const char *path) {
+        int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+            // not a regular file (pipe, directory...): the reference's fstream would fail on a directory
+            // and stream a pipe; only regular files are supported here
+            ::close(fd);
+            return false;
+        }
+        n = (size_t)st.st_size;
+        if (n) {
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) {
+                ::close(fd);
+                return false;
+            }
+            madvise(m, n, MADV_SEQUENTIAL | MADV_WILLNEED);
+            p = (const uint8_t *)m;
+            mapped = true;
+        }
+        ::close(fd);
+        ok = true;
+        return true;
+    }
+};
+
+// ---- one FASTA record as found in a file
+struct RecInfo {
+    size_t seq_off;      // first byte after the header line
+    size_t end_off;      // first byte of the next header (or file size)
+    uint64_t full_len;   // bases after stripping trailing blanks of every line
+    uint64_t nul_at;     // offset (in bases) of the first NUL byte, UINT64_MAX if none
+    bool predicted;
+};
+
+// ---- a run of source bytes that lands on consecutive store positions
+struct Piece {
+    const uint8_t *src;  // FASTA: first sequence line of the record; raw: the bytes themselves
+    const uint8_t *end;
+    uint64_t rec;        // global (pre-shard) record index it belongs to
+    uint64_t off;        // offset inside that record
+    uint64_t take;       // bases to take
+    bool lines;          // true: walk FASTA lines, false: raw bytes
+};
+
+inline const uint8_t *find_nl(const uint8_t *p, const uint8_t *end) {
+    const void *r = memchr(p, '\n', (size_t)(end - p));
+    return r ? (const uint8_t *)r : end;
+}
+
+bool header_has_predicted(const uint8_t *h, size_t n) {
+    return n >= 9 && memmem(h, n, "PREDICTED", 9) != nullptr;
+}
+
+// Header offsets of a file: offset 0 (unless line 0 is empty, which ends the file at once) and every
+// offset that follows a '\n' and holds '>'.
+void find_headers(const FileView &f, std::vector<size_t> &hdrs) {
+    hdrs.clear();
+    if (f.n == 0 || f.p[0] == '\n') return;
+    const size_t grain = 4u << 20;
+    const size_t n_chunks = (f.n + grain - 1) / grain;
+    std::vector<std::vector<size_t>> part(n_chunks);
+    parallel_for(n_chunks, 1, [&](size_t lo, size_t hi) {
+        for (size_t c = lo; c < hi; ++c) {
+            const uint8_t *a = f.p + c * grain;
+            const uint8_t *b = f.p + std::min(f.n, (c + 1) * grain);
+            const uint8_t *last = f.p + f.n - 1;  // a '\n' here has nothing after it
+            auto &out = part[c];
+            while (a < b) {
+                const uint8_t *nl = (const uint8_t *)memchr(a, '\n', (size_t)(b - a));
+                if (!nl) break;
+                if (nl < last && nl[1] == '>') out.push_back((size_t)(nl + 1 - f.p));
+                a = nl + 1;
+            }
+        }
+    });
+    hdrs.push_back(0);
+    for (auto &v : part) hdrs.insert(hdrs.end(), v.begin(), v.end());
+}
+
+void analyse_records(const FileView &f, const std::vector<size_t> &hdrs, bool want_nul, std::vector<RecInfo> &recs) {
+    recs.resize(hdrs.size());
+    parallel_for(hdrs.size(), 256, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const uint8_t *h = f.p + hdrs[i];
+            const uint8_t *end = f.p + ((i + 1 < hdrs.size()) ? hdrs[i + 1] : f.n);
+            const uint8_t *he = find_nl(h, end);
+            RecInfo r;
+            r.predicted = header_has_predicted(h, (size_t)(he - h));
+            const uint8_t *p = (he < end) ? he + 1 : end;
+            r.seq_off = (size_t)(p - f.p);
+            r.end_off = (size_t)(end - f.p);
+            r.full_len = 0;
+            r.nul_at = UINT64_MAX;
+            while (p < end) {
+                const uint8_t *e = find_nl(p, end);
+                size_t ln = (size_t)(e - p);
+                while (ln > 0 && p[ln - 1] == ' ') --ln;
+                if (want_nul && r.nul_at == UINT64_MAX && ln) {
+                    const void *z = memchr(p, 0, ln);
+                    if (z) r.nul_at = r.full_len + (uint64_t)((const uint8_t *)z - p);
+                }
+                r.full_len += ln;
+                p = (e < end) ? e + 1 : end;
+            }
+            recs[i] = r;
+        }
+    });
+}
+
+// ---- streaming packer: appends bases at consecutive positions of the store arrays.
+// Words completely covered by one piece are written with plain stores; the first and last word a piece
+// touches may be shared with a neighbouring piece handled by another thread and are OR-ed in atomically.
+class StreamPacker {
+  public:
+    StreamPacker(uint32_t *bases, uint32_t *valid, uint64_t pos) : B(bases), V(valid), pos_(pos) {
+        b_shared_ = (pos & 15) != 0;
+        v_shared_ = (pos & 31) != 0;
+    }
+    void push(const uint8_t *s, size_t n) {
+        uint64_t pos = pos_;
+        uint32_t bw = bw_, vw = vw_;
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t c = g_codes.t[s[i]];
+            const uint32_t ok = c < 4;
+            bw |= (c & 3u) << (30 - 2 * (pos & 15));
+            vw |= ok << (pos & 31);
+            ++pos;
+            if ((pos & 15) == 0) {
+                store(B + (pos - 1) / 16, bw, b_shared_);
+                b_shared_ = false;
+                bw = 0;
+            }
+            if ((pos & 31) == 0) {
+                store(V + (pos - 1) / 32, vw, v_shared_);
+                v_shared_ = false;
+                vw = 0;
+            }
+        }
+        pos_ = pos;
+        bw_ = bw;
+        vw_ = vw;
+    }
+    void finish() {
+        if (pos_ & 15) store(B + pos_ / 16, bw_, true);
+        if (pos_ & 31) store(V + pos_ / 32, vw_, true);
+        bw_ = vw_ = 0;
+    }
+
+  private:
+    static void store(uint32_t *w, uint32_t v, bool shared) {
+        if (shared) {
+            if (v) __atomic_fetch_or(w, v, __ATOMIC_RELAXED);
+        } else {
+            *w = v;
+        }
+    }
+    uint32_t *B, *V;
+    uint64_t pos_;
+    uint32_t bw_ = 0, vw_ = 0;
+    bool b_shared_, v_shared_;
+};
+
+void pack_piece(const Piece &pc, uint64_t dst, uint32_t *bases, uint32_t *valid) {
+    if (pc.take == 0) return;
+    StreamPacker sp(bases, valid, dst);
+    uint64_t left = pc.take;
+    if (!pc.lines) {
+        sp.push(pc.src, (size_t)left);
+    } else {
+        const uint8_t *p = pc.src;
+        while (p < pc.end && left) {
+            const uint8_t *e = find_nl(p, pc.end);
+            size_t ln = (size_t)(e - p);
+            while (ln > 0 && p[ln - 1] == ' ') --ln;
+            if (ln > left) ln = (size_t)left;
+            sp.push(p, ln);
+            left -= ln;
+            p = (e < pc.end) ? e + 1 : pc.end;
+        }
+    }
+    sp.finish();
+}
+
+// ---- FASTQ(.gz): restates get_sequence_fastq_gz (reference src/libkmers.cpp:240-300) as a line state machine.
+// Lines 1, 5, 9, ... (0-based) of the inflated stream, '\n'-terminated ones only, joined with nothing in between.
+// The reference reads through an 8192-byte window and returns an empty sequence as soon as a line does not fit
+// in it, i.e. when any line (terminated or not) is 8192 bytes or longer; so does this.
+bool read_fastq_sequence(const char *path, std::vector<uint8_t> &seq) {
+    seq.clear();
+    gzFile in = gzopen(path, "rb");
+    if (!in) {
+        fprintf(stderr, "Invalid file: %s\n", path);
+        return false;
+    }
+    gzbuffer(in, 1u << 20);
+    std::vector<uint8_t> buf(1u << 20);
+    uint64_t line_no = 0;
+    size_t line_len = 0;    // bytes of the current line seen so far
+    size_t committed = 0;   // seq.size() at the start of the current (uncommitted) sequence line
+    bool bad = false;
+    int got;
+    while (!bad && (got = gzread(in, buf.data(), (unsigned)buf.size())) > 0) {
+        const uint8_t *p = buf.data(), *end = p + got;
+        while (p < end) {
+            const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
+            const uint8_t *e = nl ? nl : end;
+            const size_t n = (size_t)(e - p);
+            if (line_len + n >= 8192) {
+                bad = true;
+                break;
+            }
+            if ((line_no & 3) == 1) seq.insert(seq.end(), p, e);
+            line_len += n;
+            if (!nl) break;
+            // line complete
+            if ((line_no & 3) == 1) committed = seq.size();
+            ++line_no;
+            line_len = 0;
+            p = nl + 1;
+        }
+    }
+    if (got < 0) {
+        int err;
+        fprintf(stderr, "%s\n", gzerror(in, &err));
+        bad = true;
+    }
+    if (gzclose(in) != Z_OK) {
+        fprintf(stderr, "failed gzclose\n");
+        bad = true;
+    }
+    if (bad) {
+        seq.clear();
+        return false;
+    }
+    seq.resize(committed);  // drop an unterminated tail
+    return true;
+}
+
+void *alloc_words(size_t words, bool *pinned) {
+    void *p = nullptr;
+    *pinned = false;
+    const size_t bytes = words * sizeof(uint32_t);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) {
+            *pinned = true;
+            return p;
+        }
+        (void)hipGetLastError();
+        p = nullptr;
+    } else {
+        (void)hipGetLastError();
+    }
+    if (posix_memalign(&p, 4096, bytes ? bytes : 4096) != 0) return nullptr;
+    return p;
+}
+
+void free_words(void *p, bool pinned) {
+    if (!p) return;
+    if (pinned)
+        (void)hipHostFree(p);
+    else
+        free(p);
+}
+
+}  // namespace
+
+extern "C" {
+
+int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int shard, int n_shards,
+                       kmers_store **out) {
+    if (!out) return KMERS_ERR_BAD_ARG;
+    *out = nullptr;
+    if (n_files < 0 || (n_files > 0 && !fnames) || mode < KMERS_MODE_X || mode > KMERS_MODE_Y_FASTQ || n_shards < 1 ||
+        shard < 0 || shard >= n_shards)
+        return KMERS_ERR_BAD_ARG;
+
+    const bool fastq = (mode == KMERS_MODE_Y_FASTQ);
+    const bool cat = (mode == KMERS_MODE_X_CAT);
+    const bool xmode = (mode == KMERS_MODE_X || cat);
+    const bool l_skips_all = xmode && L < 0;  // unsigned comparison in the reference
+
+    // Everything that must outlive parsing: the mapped files and the inflated FASTQ sequences.
+    std::vector<std::unique_ptr<FileView>> files((size_t)n_files);
+    std::vector<std::vector<uint8_t>> fq((size_t)(fastq ? n_files : 0));
+    std::vector<uint64_t> rec_len;  // global (pre-shard) record lengths
+    std::vector<Piece> pieces;      // in global record order
+
+    if (fastq) {
+        parallel_for((size_t)n_files, 1, [&](size_t lo, size_t hi) {
+            for (size_t f = lo; f < hi; ++f) read_fastq_sequence(fnames[f], fq[f]);
+        });
+        for (int f = 0; f < n_files; ++f) {
+            pieces.push_back(Piece{fq[f].data(), fq[f].data() + fq[f].size(), (uint64_t)f, 0, fq[f].size(), false});
+            rec_len.push_back(fq[f].size());
+        }
+    } else {
+        std::vector<size_t> hdrs;
+        std::vector<RecInfo> recs;
+        for (int f = 0; f < n_files; ++f) {
+            files[f].reset(new FileView());
+            FileView &fv = *files[f];
+            if (!fv.open(fnames[f])) {
+                if (cat) {  // reference src/libkmers.cpp:402-403: the job just returns, the column stays empty
+                    rec_len.push_back(0);
+                    continue;
+                }
+                return KMERS_ERR_OPEN;  // reference src/libkmers.cpp:356-357, 440-441
+            }
+            if (getenv("KMERS_VERBOSE")) printf("processing %s\n", fnames[f]);
+            find_headers(fv, hdrs);
+            analyse_records(fv, hdrs, xmode, recs);
+            if (cat) {
+                uint64_t full = 0, nul = UINT64_MAX;
+                for (const RecInfo &r : recs) {
+                    if (r.predicted) continue;
+                    if (nul == UINT64_MAX && r.nul_at != UINT64_MAX) nul = full + r.nul_at;
+                    full += r.full_len;
+                }
+                uint64_t eff = (l_skips_all || full < (uint64_t)(L < 0 ? 0 : L)) ? 0 : std::min(full, nul);
+                const uint64_t rec = rec_len.size();
+                uint64_t off = 0;
+                for (const RecInfo &r : recs) {
+                    if (r.predicted || off >= eff) continue;
+                    const uint64_t take = std::min<uint64_t>(r.full_len, eff - off);
+                    if (take) pieces.push_back(Piece{fv.p + r.seq_off, fv.p + r.end_off, rec, off, take, true});
+                    off += r.full_len;
+                }
+                rec_len.push_back(eff);
+            } else {
+                for (const RecInfo &r : recs) {
+                    if (r.predicted) continue;
+                    if (xmode && (l_skips_all || r.full_len < (uint64_t)L)) continue;
+                    const uint64_t len = xmode ? std::min(r.full_len, r.nul_at) : r.full_len;
+                    const uint64_t rec = rec_len.size();
+                    if (len) pieces.push_back(Piece{fv.p + r.seq_off, fv.p + r.end_off, rec, 0, len, true});
+                    rec_len.push_back(len);
+                }
+            }
+        }
+    }
+
+    // ---- shard selection: contiguous record ranges with about equal numbers of positions
+    const uint64_t n_total = rec_len.size();
+    uint64_t pos_total = 0;
+    for (uint64_t l : rec_len) pos_total += l + 1;
+    uint64_t r_lo = 0, r_hi = n_total;
+    if (n_shards > 1) {
+        // record r belongs to shard floor(start_pos(r) * n_shards / pos_total)
+        auto bound = [&](int s) -> uint64_t {  // first record of shard s
+            if (s <= 0) return 0;
+            if (s >= n_shards) return n_total;
+            const long double target = (long double)pos_total * s / n_shards;
+            uint64_t acc = 0, r = 0;
+            for (; r < n_total; ++r) {
+                if ((long double)acc >= target) break;
+                acc += rec_len[r] + 1;
+            }
+            return r;
+        };
+        r_lo = bound(shard);
+        r_hi = bound(shard + 1);
+    }
+
+    std::unique_ptr<kmers_store> st(new (std::nothrow) kmers_store());
+    if (!st) return KMERS_ERR_NOMEM;
+    st->n_rec_total = n_total;
+    st->first_rec = r_lo;
+    st->rec_start.resize((size_t)(r_hi - r_lo) + 1);
+    uint64_t acc = 0;
+    for (uint64_t r = r_lo; r < r_hi; ++r) {
+        st->rec_start[(size_t)(r - r_lo)] = acc;
+        acc += rec_len[r] + 1;
+    }
+    st->rec_start[(size_t)(r_hi - r_lo)] = acc;
+    const uint64_t n_pos = acc;
+    st->bases_words = (size_t)((n_pos + 15) / 16) + 4;
+    st->valid_words = (size_t)((n_pos + 31) / 32) + 4;
+    bool pin_b = false, pin_v = false;
+    st->bases = (uint32_t *)alloc_words(st->bases_words, &pin_b);
+    st->valid = (uint32_t *)alloc_words(st->valid_words, &pin_v);
+    if (!st->bases || !st->valid || pin_b != pin_v) {
+        free_words(st->bases, pin_b);
+        free_words(st->valid, pin_v);
+        st->bases = st->valid = nullptr;
+        return KMERS_ERR_NOMEM;
+    }
+    st->pinned = pin_b;
+
+    // zero + pack, in parallel
+    {
+        const size_t zg = 1u << 20;
+        parallel_for(st->bases_words, zg, [&](size_t lo, size_t hi) { memset(st->bases + lo, 0, (hi - lo) * 4); });
+        parallel_for(st->valid_words, zg, [&](size_t lo, size_t hi) { memset(st->valid + lo, 0, (hi - lo) * 4); });
+    }
+    // pieces of this shard: records are ascending in `pieces`, find the range by binary search
+    auto plo = std::lower_bound(pieces.begin(), pieces.end(), r_lo,
+                                [](const Piece &p, uint64_t r) { return p.rec < r; });
+    auto phi = std::lower_bound(pieces.begin(), pieces.end(), r_hi,
+                                [](const Piece &p, uint64_t r) { return p.rec < r; });
+    const size_t np = (size_t)(phi - plo);
+    const Piece *pp = np ? &*plo : nullptr;
+    // grain: aim at ~1 MiB of bases per chunk for typical transcript lengths, 1 piece minimum
+    size_t grain = 1;
+    if (np) {
+        const uint64_t avg = std::max<uint64_t>(1, (n_pos) / np);
+        grain = (size_t)std::max<uint64_t>(1, (1u << 20) / avg);
+    }
+    parallel_for(np, grain, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const Piece &pc = pp[i];
+            pack_piece(pc, st->rec_start[(size_t)(pc.rec - r_lo)] + pc.off, st->bases, st->valid);
+        }
+    });
+
+    *out = st.release();
+    return KMERS_OK;
+}
+
+void kmers_store_free(kmers_store *s) {
+    if (!s) return;
+    free_words(s->bases, s->pinned);
+    free_words(s->valid, s->pinned);
+    delete s;
+}
+
+uint64_t kmers_store_n_pos(const kmers_store *s) { return s->rec_start.back(); }
+uint64_t kmers_store_n_rec(const kmers_store *s) { return s->rec_start.size() - 1; }
+uint64_t kmers_store_n_rec_total(const kmers_store *s) { return s->n_rec_total; }
+uint64_t kmers_store_first_rec(const kmers_store *s) { return s->first_rec; }
+uint64_t kmers_store_n_bases(const kmers_store *s) { return s->rec_start.back() - (s->rec_start.size() - 1); }
+uint64_t kmers_store_n_windows(const kmers_store *s, int K) {
+    uint64_t w = 0;
+    for (size_t r = 0; r + 1 < s->rec_start.size(); ++r) {
+        const uint64_t len = s->rec_start[r + 1] - s->rec_start[r] - 1;
+        if (K >= 1 && len >= (uint64_t)K) w += len - (uint64_t)K + 1;
+    }
+    return w;
+}
+const uint32_t *kmers_store_bases(const kmers_store *s) { return s->bases; }
+const uint32_t *kmers_store_valid(const kmers_store *s) { return s->valid; }
+const uint64_t *kmers_store_rec_start(const kmers_store *s) { return s->rec_start.data(); }
+size_t kmers_store_bases_words(const kmers_store *s) { return s->bases_words; }
+size_t kmers_store_valid_words(const kmers_store *s) { return s->valid_words; }
+
+}  // extern "C"

@@ -1,0 +1,31 @@
+// kernels.hpp -- host-callable launchers of kernels.hip (internal to libkmers.so).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+#include <vector>
+
+namespace kk {
+
+struct ProfEntry {
+    std::string name;
+    double ms;
+    uint64_t calls;
+};
+void profile_enable(bool on);
+void profile_reset();
+std::vector<ProfEntry> profile_snapshot();
+
+size_t x_workspace_bytes(uint64_t n_pos, uint64_t n_rec, int K);
+
+// Both return 0 or a KMERS_ERR_* code (include/kmers_hip.h).
+int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words, uint64_t n_pos, int K,
+            int32_t *d_counts, hipStream_t s);
+
+int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words, const uint64_t *d_rec_start,
+            uint64_t n_pos, uint64_t n_rec, uint64_t first_col, int K, float *d_data, uint64_t *d_col_ind, uint64_t *d_row_ind,
+            uint64_t max_nz, void *d_ws, size_t ws_bytes, uint64_t *nnz_out, hipStream_t s);
+
+}  // namespace kk

@@ -1,0 +1,288 @@
+// libkmers.cpp -- the C ABI of libkmers.so: the reference's six entry points (include/libkmers.h) and the
+// device-resident stages behind them (include/kmers_hip.h).
+//
+// Drop-in flow of the four file-level calls:
+//   host ingest (ingest.cpp: mmap, all host threads, 2-bit pack into pinned memory)
+//     -> one H2D copy of the packed store (3 bits per base)
+//     -> HIP kernels (kernels.hip)
+//     -> D2H of the result into the caller's numpy buffers.
+// There is no CPU compute path: without a GPU these calls return KMERS_ERR_NO_DEVICE.
+#include "kmers_hip.h"
+#include "kernels.hpp"
+#include "store.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+namespace {
+
+#define API_HIP(expr)                                                                                            \
+    do {                                                                                                         \
+        hipError_t e_ = (expr);                                                                                  \
+        if (e_ != hipSuccess) {                                                                                  \
+            fprintf(stderr, "libkmers: HIP error %s at %s:%d (%s)\n", hipGetErrorString(e_), __FILE__, __LINE__, \
+                    #expr);                                                                                      \
+            return KMERS_ERR_HIP;                                                                                \
+        }                                                                                                        \
+    } while (0)
+
+// 0..3 for A,C,G,T, -1 otherwise (reference src/libkmers.cpp:199-211)
+struct BaseIds {
+    signed char t[256];
+    BaseIds() {
+        memset(t, -1, sizeof t);
+        t[(unsigned char)'A'] = 0;
+        t[(unsigned char)'C'] = 1;
+        t[(unsigned char)'G'] = 2;
+        t[(unsigned char)'T'] = 3;
+    }
+};
+const BaseIds g_ids;
+
+struct StoreGuard {
+    kmers_store *s = nullptr;
+    ~StoreGuard() { kmers_store_free(s); }
+};
+
+// device buffers that free themselves
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 256); }
+    template <class T>
+    T *as() const {
+        return (T *)p;
+    }
+};
+
+int select_device() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return KMERS_ERR_NO_DEVICE;
+    }
+    if (const char *e = getenv("KMERS_DEVICE")) {
+        const int d = atoi(e);
+        if (d < 0 || d >= n) return KMERS_ERR_BAD_ARG;
+        if (hipSetDevice(d) != hipSuccess) return KMERS_ERR_HIP;
+    }
+    return KMERS_OK;
+}
+
+struct DevStore {
+    DevBuf bases, valid, rec_start;
+    int upload(const kmers_store *st, bool with_records, hipStream_t s) {
+        API_HIP(bases.alloc(st->bases_words * 4));
+        API_HIP(valid.alloc(st->valid_words * 4));
+        API_HIP(hipMemcpyAsync(bases.p, st->bases, st->bases_words * 4, hipMemcpyHostToDevice, s));
+        API_HIP(hipMemcpyAsync(valid.p, st->valid, st->valid_words * 4, hipMemcpyHostToDevice, s));
+        if (with_records) {
+            API_HIP(rec_start.alloc(st->rec_start.size() * 8));
+            API_HIP(hipMemcpyAsync(rec_start.p, st->rec_start.data(), st->rec_start.size() * 8, hipMemcpyHostToDevice, s));
+        }
+        return KMERS_OK;
+    }
+};
+
+int count_files(int n_files, const char *fnames[], int K, int *counts, int mode) {
+    if (K < 1 || K > 16 || !counts || n_files < 0) return KMERS_ERR_BAD_ARG;
+    StoreGuard g;
+    if (int rc = kmers_store_ingest(n_files, fnames, mode, 0, 0, 1, &g.s)) return rc;
+    if (int rc = select_device()) return rc;
+    const kmers_store *st = g.s;
+    const uint64_t n_pos = kmers_store_n_pos(st);
+    if (n_pos == 0) return KMERS_OK;
+    const uint64_t M = 1ull << (2 * K);
+    hipStream_t s = nullptr;
+    DevStore ds;
+    if (int rc = ds.upload(st, false, s)) return rc;
+    DevBuf dc;
+    API_HIP(dc.alloc(M * 4));
+    API_HIP(hipMemsetAsync(dc.p, 0, M * 4, s));
+    if (int rc = kk::count_y(ds.bases.as<uint32_t>(), st->bases_words, ds.valid.as<uint32_t>(), st->valid_words, n_pos, K,
+                             dc.as<int32_t>(), s))
+        return rc;
+    // the reference only ever increments the caller's array (src/libkmers.cpp:213-216): add, do not overwrite
+    std::unique_ptr<int32_t[]> h(new (std::nothrow) int32_t[M]);
+    if (!h) return KMERS_ERR_NOMEM;
+    API_HIP(hipMemcpyAsync(h.get(), dc.p, M * 4, hipMemcpyDeviceToHost, s));
+    API_HIP(hipStreamSynchronize(s));
+    const int32_t *src = h.get();
+    kmers::parallel_for((size_t)M, 1u << 20, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) counts[i] += src[i];
+    });
+    return KMERS_OK;
+}
+
+int build_files(int n_files, const char *fnames[], int K, int L, int mode, float *data, uint64_t *row_ind, uint64_t *col_ind,
+                uint64_t max_size, uint64_t *nnz, int *n_cols) {
+    if (K < 1 || K > 16 || !row_ind || !nnz || !n_cols || n_files < 0 || (max_size && (!data || !col_ind)))
+        return KMERS_ERR_BAD_ARG;
+    StoreGuard g;
+    if (int rc = kmers_store_ingest(n_files, fnames, mode, L, 0, 1, &g.s)) return rc;
+    if (int rc = select_device()) return rc;
+    const kmers_store *st = g.s;
+    const uint64_t n_pos = kmers_store_n_pos(st), n_rec = kmers_store_n_rec(st);
+    if (n_pos > 0xFFFFFFFEull || n_rec > 0x7FFFFFFFull) return KMERS_ERR_TOO_LARGE;
+    const uint64_t M = 1ull << (2 * K);
+    const uint64_t windows = kmers_store_n_windows(st, K);   // upper bound on nnz
+    const uint64_t cap = std::min<uint64_t>(max_size, windows);
+    hipStream_t s = nullptr;
+    DevStore ds;
+    if (int rc = ds.upload(st, true, s)) return rc;
+    DevBuf d_data, d_col, d_row, d_ws;
+    const size_t ws_bytes = kk::x_workspace_bytes(n_pos, n_rec, K);
+    API_HIP(d_data.alloc(cap * 4));
+    API_HIP(d_col.alloc(cap * 8));
+    API_HIP(d_row.alloc((M + 1) * 8));
+    API_HIP(d_ws.alloc(ws_bytes));
+    uint64_t nz = 0;
+    const int rc = kk::build_x(ds.bases.as<uint32_t>(), st->bases_words, ds.valid.as<uint32_t>(), st->valid_words,
+                               ds.rec_start.as<uint64_t>(), n_pos, n_rec, 0, K, d_data.as<float>(), d_col.as<uint64_t>(),
+                               d_row.as<uint64_t>(), cap, d_ws.p, ws_bytes, &nz, s);
+    if (rc == KMERS_ERR_MAX_NZ && nz <= max_size) {
+        fprintf(stderr, "libkmers: internal error: nnz %llu above the window count %llu\n", (unsigned long long)nz,
+                (unsigned long long)windows);
+        return KMERS_ERR_HIP;
+    }
+    if (rc) return rc;
+    API_HIP(hipMemcpyAsync(row_ind, d_row.p, (M + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (nz) {
+        API_HIP(hipMemcpyAsync(col_ind, d_col.p, nz * 8, hipMemcpyDeviceToHost, s));
+        API_HIP(hipMemcpyAsync(data, d_data.p, nz * 4, hipMemcpyDeviceToHost, s));
+    }
+    API_HIP(hipStreamSynchronize(s));
+    *nnz = nz;
+    *n_cols = (int)kmers_store_n_rec_total(st);
+    return KMERS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- the reference's six symbols ----------------------------------------------------------------------
+
+uint32_t kmer_to_id(const char *kmer, int len) {
+    // reference src/libkmers.cpp:331-337: id = id*4 + table[byte]; a non-ACGT byte adds the table's -1
+    uint32_t id = 0;
+    for (int i = 0; i < len; ++i) id = id * 4u + (uint32_t)(int)g_ids.t[(unsigned char)kmer[i]];
+    return id;
+}
+
+bool valid_kmer(const char *kmer, int len) {
+    for (int i = 0; i < len; ++i)
+        if (g_ids.t[(unsigned char)kmer[i]] < 0) return false;
+    return true;
+}
+
+int fasta_count_kmers(int n_files, const char *fnames[], int K, int *total_kmer_counts) {
+    return count_files(n_files, fnames, K, total_kmer_counts, KMERS_MODE_Y_FASTA);
+}
+
+int fastq_gz_count_kmers(int n_files, const char *fnames[], int K, int *total_kmer_counts) {
+    return count_files(n_files, fnames, K, total_kmer_counts, KMERS_MODE_Y_FASTQ);
+}
+
+int fasta_to_kmers_csr(int n_files, const char *fnames[], int K, int L, float *data, uint64_t *row_ind, uint64_t *col_ind,
+                       uint64_t max_size, uint64_t *nnz, int *n_cols) {
+    return build_files(n_files, fnames, K, L, KMERS_MODE_X, data, row_ind, col_ind, max_size, nnz, n_cols);
+}
+
+int fasta_to_kmers_csr_cat_subseq(int n_files, const char *fnames[], int K, int L, float *data, uint64_t *row_ind,
+                                  uint64_t *col_ind, uint64_t max_size, uint64_t *nnz, int *n_cols) {
+    return build_files(n_files, fnames, K, L, KMERS_MODE_X_CAT, data, row_ind, col_ind, max_size, nnz, n_cols);
+}
+
+// ---- device-resident stages ----------------------------------------------------------------------------
+
+int kmers_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int kmers_hip_count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words, uint64_t n_pos,
+                      int K, int32_t *d_counts, void *stream) {
+    if (K < 1 || K > 16 || !d_counts || (n_pos && (!d_bases || !d_valid))) return KMERS_ERR_BAD_ARG;
+    if (bases_words < (n_pos + 15) / 16 || valid_words < (n_pos + 31) / 32) return KMERS_ERR_BAD_ARG;
+    return kk::count_y(d_bases, bases_words, d_valid, valid_words, n_pos, K, d_counts, (hipStream_t)stream);
+}
+
+size_t kmers_hip_x_workspace_bytes(uint64_t n_pos, uint64_t n_rec, int K) {
+    if (K < 1 || K > 16) return 0;
+    return kk::x_workspace_bytes(n_pos, n_rec, K);
+}
+
+int kmers_hip_build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words,
+                      const uint64_t *d_rec_start, uint64_t n_pos, uint64_t n_rec, uint64_t first_col, int K, float *d_data,
+                      uint64_t *d_col_ind, uint64_t *d_row_ind, uint64_t max_nz, void *d_workspace, size_t workspace_bytes,
+                      uint64_t *nnz_out, void *stream) {
+    if (K < 1 || K > 16 || !d_row_ind || !nnz_out || !d_workspace) return KMERS_ERR_BAD_ARG;
+    if (n_pos && (!d_bases || !d_valid || !d_rec_start)) return KMERS_ERR_BAD_ARG;
+    if (max_nz && (!d_data || !d_col_ind)) return KMERS_ERR_BAD_ARG;
+    if (bases_words < (n_pos + 15) / 16 || valid_words < (n_pos + 31) / 32) return KMERS_ERR_BAD_ARG;
+    if (n_pos > 0xFFFFFFFEull || n_rec > 0x7FFFFFFFull) return KMERS_ERR_TOO_LARGE;
+    return kk::build_x(d_bases, bases_words, d_valid, valid_words, d_rec_start, n_pos, n_rec, first_col, K, d_data, d_col_ind,
+                       d_row_ind, max_nz, d_workspace, workspace_bytes, nnz_out, (hipStream_t)stream);
+}
+
+// ---- per-kernel timing (HIP events on the launch stream) ------------------------------------------------------
+
+void kmers_hip_profile_enable(int on) {
+    kk::profile_enable(on != 0);
+    if (on) kk::profile_reset();
+}
+
+int kmers_hip_profile_count(void) { return (int)kk::profile_snapshot().size(); }
+
+int kmers_hip_profile_get(int i, char *name, size_t name_cap, double *ms_total, uint64_t *calls) {
+    const auto snap = kk::profile_snapshot();
+    if (i < 0 || (size_t)i >= snap.size() || !name || !name_cap || !ms_total || !calls) return KMERS_ERR_BAD_ARG;
+    snprintf(name, name_cap, "%s", snap[(size_t)i].name.c_str());
+    *ms_total = snap[(size_t)i].ms;
+    *calls = snap[(size_t)i].calls;
+    return KMERS_OK;
+}
+
+// ---- host merge of per-shard CSRs -------------------------------------------------------------------------
+
+int kmers_csr_merge(int n_parts, uint64_t n_rows, const float *const data[], const uint64_t *const row_ind[],
+                    const uint64_t *const col_ind[], float *out_data, uint64_t *out_row_ind, uint64_t *out_col_ind) {
+    if (n_parts < 1 || !data || !row_ind || !col_ind || !out_row_ind) return KMERS_ERR_BAD_ARG;
+    // out_row_ind[r] = sum over parts of row_ind_g[r]  (each part's pointer is its own exclusive prefix)
+    kmers::parallel_for((size_t)n_rows + 1, 1u << 18, [&](size_t lo, size_t hi) {
+        for (size_t r = lo; r < hi; ++r) {
+            uint64_t s = 0;
+            for (int g = 0; g < n_parts; ++g) s += row_ind[g][r];
+            out_row_ind[r] = s;
+        }
+    });
+    kmers::parallel_for((size_t)n_rows, 1u << 14, [&](size_t lo, size_t hi) {
+        for (size_t r = lo; r < hi; ++r) {
+            uint64_t at = out_row_ind[r];
+            for (int g = 0; g < n_parts; ++g) {
+                const uint64_t a = row_ind[g][r], b = row_ind[g][r + 1];
+                if (b > a) {
+                    memcpy(out_col_ind + at, col_ind[g] + a, (size_t)(b - a) * 8);
+                    memcpy(out_data + at, data[g] + a, (size_t)(b - a) * 4);
+                    at += b - a;
+                }
+            }
+        }
+    });
+    return KMERS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,28 @@
+"""`transcriptome_to_x` / `load_xy` with the reference's signatures and .npz output
+(reference kmerexpr/transcriptome_reader.py:6-41), on the HIP build of libkmers."""
+import numpy as np
+from scipy.sparse import csr_matrix, load_npz, save_npz
+
+from .libkmers import fasta_to_kmers_csr
+
+
+def load_xy(x_file, y_file):
+    """reference kmerexpr/transcriptome_reader.py:6-16"""
+    x = x_file if isinstance(x_file, csr_matrix) else load_npz(x_file)
+    y = y_file if isinstance(y_file, np.ndarray) else load_npz(y_file).toarray().squeeze()
+    return x, y
+
+
+def transcriptome_to_x(K, fasta_files, x_file="", L=0, max_nz=0, float_t=np.float32, concatenate_subseq=False):
+    """X = P(k-mer | isoform) as a scipy CSR matrix of shape (4**K, n_cols), float32
+    (reference kmerexpr/transcriptome_reader.py:19-41).  If x_file is given the matrix is also saved there as an
+    uncompressed scipy .npz, exactly as the reference does."""
+    if float_t != np.float32:
+        raise ValueError("Only float_t=np.float32 currently supported for fast reader")
+    M = 4 ** K
+    data, row_ind, col_ind, n_cols = fasta_to_kmers_csr(fasta_files, K, max_nz, L=L,
+                                                        concatenate_subseq=concatenate_subseq)
+    xt = csr_matrix((data, col_ind, row_ind), shape=(M, n_cols), dtype=float_t)
+    if x_file:
+        save_npz(x_file, xt, compressed=False)
+    return xt

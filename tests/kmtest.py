@@ -28,6 +28,9 @@ class Lib:
     """Uniform view of a library exporting the six reference symbols under an optional prefix."""
 
     def __init__(self, path, prefix=""):
+        if not prefix:
+            from kmers_amd import _lib
+            _lib._share_hip_runtime_with_torch()   # one HIP runtime per process (see kmers_amd/_lib.py)
         self.lib = C.CDLL(path)
         self.prefix = prefix
         for name in ("fasta_to_kmers_csr", "fasta_to_kmers_csr_cat_subseq"):

@@ -1,0 +1,133 @@
+"""Host ingest (kmers_amd/csrc/ingest.cpp) on CPU: the packed store, decoded back to sequences and run through
+the oracle, must reproduce every golden fixture -- so record rules, filters, column numbering, NUL cut, FASTQ
+joining and the 2-bit/validity packing are all pinned without a GPU.  Also: the C-ABI library loads and exports
+every symbol that include/*.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from kmers_amd import _lib
+from kmers_amd.store import MODE_X, MODE_X_CAT, MODE_Y_FASTA, MODE_Y_FASTQ, Store
+from tests import kmtest
+
+CASES = kmtest.manifest()
+
+
+def _mode(case):
+    if case["kind"] == "x":
+        return MODE_X_CAT if case["cat"] else MODE_X
+    return MODE_Y_FASTQ if case["kind"] == "y_fastq" else MODE_Y_FASTA
+
+
+def _rewrite(seqs, path):
+    with open(path, "wb") as f:
+        for i, s in enumerate(seqs):
+            f.write(b">r%d\n" % i + s + b"\n")
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_store_roundtrip_matches_golden(oracle, case, tmp_path):
+    st = Store(kmtest.case_paths(case), _mode(case), L=case.get("L", 0))
+    seqs = st.sequences()
+    assert st.n_rec == st.n_rec_total == len(seqs)
+    assert st.n_pos == sum(len(s) + 1 for s in seqs)
+    K = case["K"]
+    assert st.n_windows(K) == sum(max(len(s) - K + 1, 0) for s in seqs)
+    p = str(tmp_path / "rt.fsa")
+    _rewrite(seqs, p)
+    if case["kind"] == "x":
+        out = oracle.x([p], K, 0, False, max_nz=st.n_pos + 16)
+        kmtest.assert_x_equal_golden(case, *out)
+    else:
+        rc, y = oracle.y([p], K)
+        kmtest.assert_y_equal_golden(case, rc, y)
+    st.close()
+
+
+def test_store_padding_is_zero():
+    st = Store([os.path.join(kmtest.INP, "syn_small.fsa")], MODE_X)
+    n = st.n_pos
+    assert st.bases.shape[0] >= (n + 15) // 16 + 4 and st.valid.shape[0] >= (n + 31) // 32 + 4
+    assert not st.bases[(n + 15) // 16:].any() and not st.valid[(n + 31) // 32:].any()
+    # separators are invalid positions
+    rs = st.rec_start.astype(np.int64)
+    sep = rs[1:] - 1
+    assert not ((st.valid[sep >> 5] >> (sep & 31).astype(np.uint32)) & 1).any()
+
+
+@pytest.mark.parametrize("n_shards", [2, 3, 8])
+def test_store_shards_partition_records(n_shards):
+    files = [os.path.join(kmtest.INP, "syn_small.fsa"), os.path.join(kmtest.INP, "ref_test4.fsa")]
+    whole = Store(files, MODE_X).sequences()
+    got, first = [], 0
+    sizes = []
+    for s in range(n_shards):
+        st = Store(files, MODE_X, shard=s, n_shards=n_shards)
+        assert st.first_rec == first and st.n_rec_total == len(whole)
+        got += st.sequences()
+        first += st.n_rec
+        sizes.append(st.n_pos)
+    assert got == whole
+    assert max(sizes) - min(sizes) <= max(len(s) for s in whole) + 1   # balanced by positions
+
+
+def test_threads_do_not_change_the_store(monkeypatch):
+    files = [os.path.join(kmtest.INP, "syn_small.fsa")]
+    monkeypatch.setenv("KMER_NUM_THREADS", "1")
+    a = Store(files, MODE_X)
+    monkeypatch.setenv("KMER_NUM_THREADS", "7")
+    b = Store(files, MODE_X)
+    assert np.array_equal(a.bases, b.bases) and np.array_equal(a.valid, b.valid)
+    assert np.array_equal(a.rec_start, b.rec_start)
+
+
+def test_ingest_errors(tmp_path):
+    missing = str(tmp_path / "nope.fsa")
+    with pytest.raises(RuntimeError, match="Failed to open FASTA"):
+        Store([missing], MODE_X)
+    with pytest.raises(RuntimeError, match="Failed to open FASTA"):
+        Store([missing], MODE_Y_FASTA)
+    st = Store([missing, os.path.join(kmtest.INP, "edge_two_a.fsa")], MODE_X_CAT)   # empty column, no error
+    assert st.n_rec == 2 and st.sequences()[0] == b""
+    st = Store([missing], MODE_Y_FASTQ)                                             # reference: stderr + empty
+    assert st.n_rec == 1 and st.n_bases == 0
+
+
+def test_negative_L_skips_everything():
+    st = Store([os.path.join(kmtest.INP, "ref_test4.fsa")], MODE_X, L=-1)   # unsigned compare in the reference
+    assert st.n_rec == 0
+
+
+def test_scalars_and_exports(product):
+    import json
+    with open(os.path.join(kmtest.GOLD, "scalars.json")) as f:
+        scal = json.load(f)
+    for w, (kid, ok) in scal.items():
+        assert product.fn("valid_kmer")(w.encode(), len(w)) == ok
+        assert product.fn("kmer_to_id")(w.encode(), len(w)) == kid
+    # every function declared in include/*.h is exported
+    lib = C.CDLL(kmtest.PRODUCT_SO)
+    names = set()
+    for h in ("libkmers.h", "kmers_hip.h"):
+        src = open(os.path.join(kmtest.ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(k?mers?_\w+|kmer_to_id|valid_kmer|fast[aq]\w+)\s*\(", src))
+    assert {"kmer_to_id", "valid_kmer", "fasta_count_kmers", "fastq_gz_count_kmers", "fasta_to_kmers_csr",
+            "fasta_to_kmers_csr_cat_subseq", "kmers_hip_build_x", "kmers_hip_count_y"} <= names
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_no_gpu_fails_loudly(product):
+    """Without a HIP device the product has no fallback: the file-level calls return KMERS_ERR_NO_DEVICE."""
+    if _lib.handle().kmers_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    p = [os.path.join(kmtest.INP, "ref_test1.fsa")]
+    assert product.x(p, 1)[0] == -10
+    assert product.y(p, 1)[0] == -10
+    from kmers_amd import transcriptome_reader as tr
+    with pytest.raises(RuntimeError, match="no usable HIP device"):
+        tr.transcriptome_to_x(1, p[0])

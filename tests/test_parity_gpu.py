@@ -1,0 +1,120 @@
+"""Parity of the HIP path (through the C ABI of kmers_amd/lib/libkmers.so) with the reference.
+
+  * every golden fixture produced by the unmodified reference library (tests/golden/) -- bit-exact;
+  * seeded random transcriptomes / reads against the oracle -- bit-exact (int32 counts, uint64 indices,
+    float32 values compared as bit patterns);
+  * the edge cases the reference has no answer for (records shorter than K-1) against the oracle's definition;
+  * error codes.
+Needs a real MI355X: run with -m gpu."""
+import os
+
+import numpy as np
+import pytest
+
+from kmers_amd import synth
+from tests import kmtest
+
+pytestmark = pytest.mark.gpu
+CASES = kmtest.manifest()
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c["kind"] == "x"], ids=lambda c: c["name"])
+def test_x_matches_reference(product, case):
+    out = product.x(kmtest.case_paths(case), case["K"], case["L"], case["cat"])
+    kmtest.assert_x_equal_golden(case, *out)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c["kind"] != "x"], ids=lambda c: c["name"])
+def test_y_matches_reference(product, case):
+    rc, y = product.y(kmtest.case_paths(case), case["K"], fastq=(case["kind"] == "y_fastq"))
+    kmtest.assert_y_equal_golden(case, rc, y)
+
+
+@pytest.fixture(scope="module")
+def syn(tmp_path_factory):
+    d = tmp_path_factory.mktemp("syn")
+    iso = str(d / "iso.fsa")
+    info = synth.synth_transcriptome(iso, n_records=3000, total_bases=3_000_000, seed=11, return_sequences=True)
+    reads = str(d / "reads.fsa")
+    synth.synth_reads(reads, info["concat"], info["offsets"], 30000, read_len=100, seed=5)
+    uni = str(d / "uni.fsa")
+    synth.synth_transcriptome(uni, n_records=500, total_bases=1_000_000, seed=3, uniform=True)
+    return dict(iso=iso, reads=reads, uni=uni)
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 7, 8, 9, 11, 12, 13])
+def test_x_random_vs_oracle(product, oracle, syn, K):
+    a = product.x([syn["iso"]], K)
+    b = oracle.x([syn["iso"]], K)
+    assert a[1].shape[0] > 0
+    kmtest.assert_x_equal(a, b)
+
+
+@pytest.mark.parametrize("K,L,cat", [(8, 1500, False), (12, 0, True), (6, 2000, True), (14, 0, False)])
+def test_x_variants_vs_oracle(product, oracle, syn, K, L, cat):
+    files = [syn["iso"], syn["uni"]]
+    kmtest.assert_x_equal(product.x(files, K, L, cat), oracle.x(files, K, L, cat))
+
+
+@pytest.mark.parametrize("K", [1, 3, 6, 7, 8, 10, 12, 14])
+def test_y_random_vs_oracle(product, oracle, syn, K):
+    rc, y = product.y([syn["reads"], syn["uni"]], K)
+    rc2, y2 = oracle.y([syn["reads"], syn["uni"]], K)
+    assert rc == rc2 == 0
+    assert int(y.sum()) > 0
+    assert np.array_equal(y, y2)
+
+
+def test_y_accumulates_into_callers_buffer(product, syn):
+    """The reference only increments the caller's array (libkmers.cpp:213-216)."""
+    rc, y = product.y([syn["reads"]], 6)
+    pre = np.full(4 ** 6, 7, np.int32)
+    rc2, y2 = product.y([syn["reads"]], 6, into=pre)
+    assert rc == rc2 == 0 and np.array_equal(y2, y + 7)
+
+
+def test_short_and_empty_records(product, oracle, tmp_path):
+    """Records shorter than K-1: the reference reads out of bounds; defined here (and in the oracle) as zero
+    k-mers, column kept."""
+    p = tmp_path / "short.fsa"
+    p.write_text(">a\nAC\n>b\n\n>c\nACGTACGTNNACGTACGTAC\n>d\nA\n>e\n>f\nACGTA\n")
+    for K in (1, 2, 5, 6, 9):
+        kmtest.assert_x_equal(product.x([str(p)], K), oracle.x([str(p)], K))
+        assert np.array_equal(product.y([str(p)], K)[1], oracle.y([str(p)], K)[1])
+    rc, data, row, col, n_cols = product.x([str(p)], 5)
+    assert rc == 0 and n_cols == 6 and set(col.tolist()) == {2, 5}
+
+
+def test_no_files_and_empty_inputs(product, tmp_path):
+    rc, data, row, col, n_cols = product.x([], 3)
+    assert rc == 0 and n_cols == 0 and data.shape[0] == 0 and not row.any()
+    e = tmp_path / "e.fsa"
+    e.write_text("")
+    rc, data, row, col, n_cols = product.x([str(e)], 3)
+    assert rc == 0 and n_cols == 0 and not row.any()
+    n = tmp_path / "n.fsa"
+    n.write_text(">a\nNNNNNNNN\n>b\nNNNN\n")
+    rc, data, row, col, n_cols = product.x([str(n)], 3)
+    assert rc == 0 and n_cols == 2 and data.shape[0] == 0 and not row.any()
+    rc, y = product.y([str(n)], 3)
+    assert rc == 0 and not y.any()
+
+
+def test_error_codes(product, tmp_path):
+    missing = str(tmp_path / "nope.fsa")
+    assert product.x([missing], 2)[0] == -1
+    assert product.y([missing], 2)[0] == -1
+    four = os.path.join(kmtest.INP, "ref_test4.fsa")
+    assert product.x([four], 2, max_nz=3)[0] == -2           # 31 non-zeros do not fit
+    assert product.x([four], 2, max_nz=31)[0] == 0           # exactly enough
+    assert product.x([four], 0)[0] == -12 and product.x([four], 17)[0] == -12
+    rc, data, row, col, n_cols = product.x([missing, four], 2, cat=True)
+    assert rc == 0 and n_cols == 2 and set(col.tolist()) == {1}
+
+
+def test_row_pointer_gap_fill_paths(product, oracle, tmp_path):
+    """Very sparse rows at large K exercise the queued (long-gap) row-pointer fill and its chunk splitting."""
+    p = tmp_path / "sparse.fsa"
+    p.write_text(">a\nAAAAAAAAAAAAAC\n>b\nTTTTTTTTTTTTTT\n>c\nCATGCATGCATGCATGCA\n")
+    for K in (11, 12, 14):
+        kmtest.assert_x_equal(product.x([str(p)], K), oracle.x([str(p)], K))
