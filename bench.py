@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the k-mer hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload x8|x14|x12|y12|y8|y14]
+
+A step = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+  x8  (default) BASELINE.json configs[1]: synthetic GRCh38-RefSeq-shaped transcriptome, ~170k isoforms / ~400 Mbases,
+      K=8 -> CSR X (kmers_hip_build_x: shred, stable radix partition, run-length reduce, emit)
+  x14 configs[2]: the same transcriptome at K=14
+  y12 configs[3] per-GPU share: simulated 100 bp reads -> dense int32 histogram at K=12 (kmers_hip_count_y)
+For N > 1 (one process per GPU, torchrun) every rank works on its own shard of the same shape (weak scaling: X column
+shards need no collective; y shards are summed with one RCCL all-reduce inside the timed step).
+Rank 0 prints ONE JSON line.  `value` is k-mers/s over all ranks, a k-mer being one window position
+(sum over records of max(len-K+1, 0)).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "k-mers/sec (transcriptome_to_x + reads->y) at K=8/14; achieved HBM GB/s"
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="x8", choices=["x8", "x12", "x14", "y8", "y12", "y14"])
+    ap.add_argument("--records", type=int, default=170_000)
+    ap.add_argument("--bases", type=int, default=400_000_000)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU for the y workloads")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cache", default=os.environ.get("KMERS_BENCH_CACHE", "/tmp/kmers_bench"))
+    return ap.parse_args()
+
+
+def make_inputs(args, rank, want_reads):
+    """Synthetic FASTA files for this rank (cached on local disk; generation is not timed)."""
+    from kmers_amd import synth
+    os.makedirs(args.cache, exist_ok=True)
+    seed = 20240521 + rank
+    iso = os.path.join(args.cache, f"tx_s{seed}_r{args.records}_b{args.bases}.fsa")
+    reads = os.path.join(args.cache, f"reads_s{42 + rank}_n{args.reads}_tx{seed}_r{args.records}_b{args.bases}.fsa")
+    need_reads = want_reads and not os.path.exists(reads)
+    if not os.path.exists(iso) or need_reads:
+        tmp = f"{iso}.tmp{os.getpid()}"
+        info = synth.synth_transcriptome(tmp, n_records=args.records, total_bases=args.bases, seed=seed,
+                                         return_sequences=need_reads)
+        os.replace(tmp, iso)
+        if need_reads:
+            tmp = f"{reads}.tmp{os.getpid()}"
+            synth.synth_reads(tmp, info["concat"], info["offsets"], args.reads, read_len=100, seed=42 + rank)
+            os.replace(tmp, reads)
+    return iso, reads
+
+
+def cpu_baseline(args, K, kind_x):
+    """The reference library itself (oracle/_ref, built in the build container from /root/reference/src) -- or, when
+    that build is absent, the oracle port -- timed on the host cores on a bounded sample of the same workload."""
+    from kmers_amd import synth
+    from tests import kmtest
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libkmers_ref.so")
+    cores = min(16, os.cpu_count() or 1)
+    os.environ["KMER_NUM_THREADS"] = str(cores)
+    if os.path.exists(ref_so):
+        lib, kind = kmtest.Lib(ref_so, ""), "reference"
+    else:
+        lib, kind, cores = kmtest.load_oracle(), "port", 1
+    n_rec, n_bases = max(100, args.records // 10), max(100_000, args.bases // 10)
+    sample = os.path.join(args.cache, f"cpu_sample_r{n_rec}_b{n_bases}.fsa")
+    info = None
+    if not os.path.exists(sample):
+        info = synth.synth_transcriptome(sample + ".tmp", n_records=n_rec, total_bases=n_bases, seed=20240521,
+                                         return_sequences=not kind_x)
+        os.replace(sample + ".tmp", sample)
+    path = sample
+    what = f"{n_rec} isoforms / {n_bases / 1e6:.0f} Mbases of the same synthetic transcriptome"
+    if not kind_x:
+        path = sample + ".reads"
+        n_reads = max(1000, args.reads // 10)
+        if not os.path.exists(path):
+            if info is None or "concat" not in info:
+                info = synth.synth_transcriptome(sample + ".tmp", n_records=n_rec, total_bases=n_bases, seed=20240521,
+                                                 return_sequences=True)
+                os.replace(sample + ".tmp", sample)
+            synth.synth_reads(path + ".tmp", info["concat"], info["offsets"], n_reads, read_len=100, seed=42)
+            os.replace(path + ".tmp", path)
+        what = f"{n_reads} simulated 100 bp reads"
+    from kmers_amd.store import MODE_X, MODE_Y_FASTA, Store
+    st = Store(path, MODE_X if kind_x else MODE_Y_FASTA)
+    windows = st.n_windows(K)
+    st.close()
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    saved = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(devnull, 1)                  # the reference prints phase timings to stdout
+    try:
+        t0 = time.perf_counter()
+        if kind_x:
+            rc = lib.x([path], K)[0]
+        else:
+            rc = lib.y([path], K)[0]
+        dt = time.perf_counter() - t0
+    finally:
+        os.dup2(saved, 1)
+        os.close(devnull)
+        os.close(saved)
+    assert rc == 0, rc
+    return {"value": windows / dt, "unit": "k-mers/s", "cores": cores, "kind": kind,
+            "sample": f"{what}, one call of {'fasta_to_kmers_csr' if kind_x else 'fasta_count_kmers'} at K={K}, "
+                      f"{dt:.1f} s wall, file in page cache"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    kind_x = args.workload[0] == "x"
+    K = int(args.workload[1:])
+
+    import torch
+    import torch.distributed as dist
+    from kmers_amd import _lib
+    from kmers_amd.store import MODE_X, MODE_Y_FASTA, Store
+
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    iso, reads = make_inputs(args, rank, want_reads=not kind_x)
+    st = Store(iso if kind_x else reads, MODE_X if kind_x else MODE_Y_FASTA)
+    ds = st.to_device(dev)
+    windows = st.n_windows(K)
+    n_bases, n_rec, n_pos = st.n_bases, st.n_rec, st.n_pos
+    M = 4 ** K
+    instances = int(ds.count_y(K).sum().item())      # valid windows (entries the X path sorts); not timed
+
+    if kind_x:
+        buf = ds.x_buffers(K, windows)
+        nnz = 0
+
+        def step():
+            nonlocal nnz
+            nnz = ds.build_x(buf)
+    else:
+        counts = torch.zeros(M, dtype=torch.int32, device=dev)
+
+        def step():
+            counts.zero_()
+            ds.count_y(K, counts)
+            if world > 1:
+                dist.all_reduce(counts)      # RCCL ring over xGMI: the reference's shared-array "+=" across GPUs
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    _lib.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    table = _lib.profile_table()
+    _lib.profile(False)
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    w = torch.tensor([float(windows)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(w, op=dist.ReduceOp.SUM)
+    dt_max, windows_all = float(t.item()), float(w.item())
+
+    if rank == 0:
+        ms_per_step = dt_max / args.steps * 1e3
+        value = windows_all * args.steps / dt_max
+        # ---- algorithmic bytes per rank
+        B = n_bases
+        if kind_x:
+            path_bytes = B / 4 + B / 8 + 8 * (n_rec + 1) + nnz * 12 + 8 * (M + 1)
+            E = instances
+            # what each kernel has to move at minimum for its own job (per launch)
+            kernel_bytes = {
+                "k_hist_bases": n_pos * 3 / 8 + 8 * (n_rec + 1),
+                "k_scatter<bases>": n_pos * 3 / 8 + 8 * (n_rec + 1) + 8 * E,
+                "k_hist_keys": 4 * E,
+                "k_scatter<keys>": 16 * E,
+                "k_rle_count": 8 * E,
+                "k_rle_emit": 8 * E + 12 * nnz + 8 * (M + 1),
+            }
+            dom = max((r for r in table if r[0] in kernel_bytes), key=lambda r: r[1], default=None)
+        else:
+            path_bytes = B / 4 + B / 8 + 4 * M
+            kernel_bytes, dom = {}, None
+        roof = None
+        if dom is not None:
+            avg_ms = dom[1] / dom[2]
+            ach = kernel_bytes[dom[0]] / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(avg_ms, 4),
+                    "algorithmic_bytes": int(kernel_bytes[dom[0]])}
+        else:
+            ach = path_bytes / (ms_per_step * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_count_y", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(ms_per_step, 4),
+                    "algorithmic_bytes": int(path_bytes)}
+        path_gbs = path_bytes / (ms_per_step * 1e-3) / 1e9
+        out = {
+            "metric": METRIC, "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"{'transcriptome_to_x' if kind_x else 'reads->y'} K={K}: "
+                                   f"{n_rec} records / {n_bases / 1e6:.0f} Mbases per GPU "
+                                   f"({'BASELINE.json configs[1]' if args.workload == 'x8' else args.workload})",
+                       "K": K, "records_per_gpu": n_rec, "bases_per_gpu": n_bases, "kmers_per_gpu": windows,
+                       "valid_instances_per_gpu": instances, "nnz_per_gpu": (nnz if kind_x else None),
+                       "parallelism": f"shards{world}"},
+            "roofline": roof,
+            "path": {"algorithmic_bytes": int(path_bytes), "bytes_per_kmer": round(path_bytes / max(windows, 1), 3),
+                     "achieved_GBs": round(path_gbs, 1), "frac_of_hbm_peak": round(path_gbs / HBM_PEAK_GBS, 4)},
+            "kernels_ms": {r[0]: round(r[1] / args.steps, 4) for r in table},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, K, kind_x)
+            except Exception as e:  # the baseline must never hide the GPU number
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
