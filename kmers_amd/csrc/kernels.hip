@@ -7,8 +7,8 @@
 //   collect_kmers (unordered_map per isoform) + fill_indices_coo (:218-238)
 //   + ThreadPoolLocalData::to_csr (sort by row, gather, sort by col, :77-169)
 //        -> "shred, stable radix partition by k-mer id, run-length reduce":
-//           k_hist_bases / k_scatter (pass 0, straight from the packed bases), k_hist_keys / k_scatter
-//           (further 8-bit digits), k_rle_count / k_rle_emit (one CSR entry per run of equal (k-mer, column),
+//           k_hist_bases / k_scatter<true> (pass 0, straight from the packed bases), k_hist_entries /
+//           k_scatter<false> (further 8-bit digits), k_rle (one CSR entry per run of equal (k-mer, column),
 //           value float(run length) / float(valid windows of the column), row pointer by gap filling).
 //
 // Why a sort and not a hash: every window instance becomes an 8-byte (k-mer id, column) entry in position
@@ -20,7 +20,10 @@
 // Geometry: 512-thread workgroups (8 wave64), a tile is 8192 entries.  Wave w of a tile owns the contiguous
 // chunk [w*1024, (w+1)*1024) and walks it in 16 rounds of 64 consecutive entries, so the order
 // (wave, round, lane) is the entry order; ranks inside a digit come from a wave-wide ballot match, which is
-// deterministic (no atomics decide an order anywhere).
+// deterministic (no atomics decide an order anywhere).  The partition kernels are persistent: a workgroup walks
+// a contiguous range of tiles and fetches tile t+1 (into registers) while tile t is ranked and written, so HBM
+// latency is paid once per workgroup, not once per tile, and neighbouring output segments of one digit are
+// written by the same CU close in time (they merge in that XCD's L2).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -41,170 +44,21 @@ constexpr int RADIX = 256;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int FILL_INLINE = 32;          // row-pointer gaps up to this many rows are filled by the finding lane
 constexpr uint64_t FILL_CHUNK = 1 << 16; // longer gaps become tasks of at most this many rows
+constexpr int PERSIST_BLOCKS = 512;      // persistent grids: two 512-thread workgroups per CU
 
+static_assert(TILE / 16 == NT, "one packed-bases word per thread per tile");
 static_assert(TILE % 64 == 0, "tile must be a whole number of wave rounds");
 
+typedef unsigned long long u64;
+
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
-__device__ __forceinline__ uint64_t lanes_below(uint32_t lane) { return (1ull << lane) - 1ull; }
+__device__ __forceinline__ u64 lanes_below(uint32_t lane) { return (1ull << lane) - 1ull; }
+__device__ __forceinline__ u64 make_entry(uint32_t key, uint32_t col) { return ((u64)key << 32) | col; }
+__device__ __forceinline__ uint32_t entry_key(u64 e) { return (uint32_t)(e >> 32); }
+__device__ __forceinline__ uint32_t entry_col(u64 e) { return (uint32_t)e; }
 
-// ------------------------------------------------------------------------------------------------------
-// Packed-bases tile: staging + record lookup + window extraction
-// ------------------------------------------------------------------------------------------------------
-
-struct BasesArgs {
-    const uint32_t *bases;
-    const uint32_t *valid;
-    const uint64_t *rec_start;  // n_rec + 1
-    uint64_t bases_words, valid_words;
-    uint64_t n_pos, n_rec;
-    int K;
-};
-
-struct BasesLds {
-    uint32_t sb[TILE / 16 + 2];     // 2-bit codes of the tile (+ overlap for windows that start near the end)
-    uint32_t sv[TILE / 32 + 2];     // validity bits
-    uint32_t sflag[TILE / 32];      // bit o set: a record starts at tile offset o (o > 0)
-    uint32_t spre[TILE / 64];       // record starts before 64-block b (exclusive prefix)
-    uint32_t c0;                    // record that contains the tile's first position
-};
-
-// Stage one tile.  All NT threads call it; ends with a barrier.  with_records = false skips the record table
-// (the y path needs no column).
-__device__ __forceinline__ void bases_tile_load(const BasesArgs &a, uint64_t tile_start, BasesLds &L, bool with_records) {
-    const uint32_t tid = threadIdx.x;
-    const uint64_t bw0 = tile_start / 16, vw0 = tile_start / 32;
-    for (uint32_t i = tid; i < TILE / 16 + 2; i += NT) {
-        const uint64_t w = bw0 + i;
-        L.sb[i] = (w < a.bases_words) ? a.bases[w] : 0u;
-    }
-    for (uint32_t i = tid; i < TILE / 32 + 2; i += NT) {
-        const uint64_t w = vw0 + i;
-        L.sv[i] = (w < a.valid_words) ? a.valid[w] : 0u;
-    }
-    if (!with_records) {
-        __syncthreads();
-        return;
-    }
-    for (uint32_t i = tid; i < TILE / 32; i += NT) L.sflag[i] = 0u;
-    // record containing tile_start: last r with rec_start[r] <= tile_start (uniform search, scalar loads)
-    uint64_t lo = 0, hi = a.n_rec;  // invariant: rec_start[lo] <= tile_start, answer in [lo, hi)
-    while (hi - lo > 1) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (a.rec_start[mid] <= tile_start)
-            lo = mid;
-        else
-            hi = mid;
-    }
-    if (tid == 0) L.c0 = (uint32_t)lo;
-    __syncthreads();
-    // mark the record starts inside (tile_start, tile_start + TILE)
-    const uint64_t tile_end = tile_start + TILE;
-    for (uint64_t base = lo + 1;; base += NT) {
-        const uint64_t c = base + tid;
-        bool in = false;
-        if (c < a.n_rec) {
-            const uint64_t rs = a.rec_start[c];
-            if (rs < tile_end) {
-                in = true;
-                const uint32_t o = (uint32_t)(rs - tile_start);
-                atomicOr(&L.sflag[o >> 5], 1u << (o & 31));
-            }
-        }
-        if (!__syncthreads_or(in && tid == NT - 1)) break;  // starts ascend: go on only while the last one was inside
-    }
-    __syncthreads();
-    if (tid < TILE / 64) {
-        uint32_t s = 0;
-        for (uint32_t b = 0; b < tid; ++b) s += __popc(L.sflag[2 * b]) + __popc(L.sflag[2 * b + 1]);
-        L.spre[tid] = s;
-    }
-    __syncthreads();
-}
-
-// Window starting at tile offset o: true iff its K positions are all valid; key = the reference's k-mer id.
-__device__ __forceinline__ bool window_at(const BasesLds &L, uint32_t o, int K, uint32_t &key) {
-    const uint32_t vi = o >> 5;
-    const uint64_t v = ((uint64_t)L.sv[vi + 1] << 32) | L.sv[vi];
-    const uint32_t need = (K == 32) ? 0xFFFFFFFFu : ((1u << K) - 1u);
-    const bool ok = ((uint32_t)(v >> (o & 31)) & need) == need;
-    const uint32_t bi = o >> 4;
-    const uint64_t x = ((uint64_t)L.sb[bi] << 32) | L.sb[bi + 1];
-    const uint32_t sh = 64u - 2u * (o & 15) - 2u * (uint32_t)K;  // >= 2 for K <= 16
-    const uint32_t mask = (K == 16) ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
-    key = (uint32_t)(x >> sh) & mask;
-    return ok;
-}
-
-// Local record index (0-based inside this store) of tile offset o.
-__device__ __forceinline__ uint32_t record_at(const BasesLds &L, uint32_t o) {
-    const uint32_t b = o >> 6, l = o & 63;
-    const uint64_t f = ((uint64_t)L.sflag[2 * b + 1] << 32) | L.sflag[2 * b];
-    const uint64_t upto = (l == 63) ? ~0ull : ((2ull << l) - 1ull);  // bits 0..l
-    return L.c0 + L.spre[b] + (uint32_t)__popcll(f & upto);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// y: dense histogram of valid windows
-// ------------------------------------------------------------------------------------------------------
-
-// One tile per loop iteration, grid-stride.  Global atomics: the table (4^K int32) lives in L2 / Infinity Cache
-// for K <= 12; int32 sums are order-independent, so the result is bit-exact whatever the interleaving.
-__global__ __launch_bounds__(NT) void k_count_y_global(BasesArgs a, int32_t *counts, uint64_t n_tiles) {
-    __shared__ BasesLds L;
-    const uint32_t w = threadIdx.x >> 6, lane = lane_id();
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        bases_tile_load(a, tile * TILE, L, false);
-#pragma unroll 4
-        for (int j = 0; j < IPT; ++j) {
-            const uint32_t o = w * WCHUNK + j * 64 + lane;
-            uint32_t key;
-            if (window_at(L, o, a.K, key)) atomicAdd(&counts[key], 1);
-        }
-        __syncthreads();
-    }
-}
-
-// Small tables (4^K <= 16384 bins, K <= 7): privatise the histogram in LDS, flush once per workgroup.
-__global__ __launch_bounds__(NT) void k_count_y_lds(BasesArgs a, int32_t *counts, uint64_t n_tiles, uint32_t n_bins) {
-    __shared__ BasesLds L;
-    __shared__ uint32_t h[16384];
-    const uint32_t w = threadIdx.x >> 6, lane = lane_id();
-    for (uint32_t i = threadIdx.x; i < n_bins; i += NT) h[i] = 0;
-    __syncthreads();
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        bases_tile_load(a, tile * TILE, L, false);
-#pragma unroll 4
-        for (int j = 0; j < IPT; ++j) {
-            const uint32_t o = w * WCHUNK + j * 64 + lane;
-            uint32_t key;
-            if (window_at(L, o, a.K, key)) atomicAdd(&h[key], 1u);
-        }
-        __syncthreads();
-    }
-    for (uint32_t i = threadIdx.x; i < n_bins; i += NT) {
-        const uint32_t v = h[i];
-        if (v) atomicAdd(&counts[i], (int32_t)v);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// X pass structure: per-tile digit histogram -> exclusive scan -> stable scatter
-// ------------------------------------------------------------------------------------------------------
-
-// Lanes of the wave whose (ok, digit) equals this lane's; 0 for lanes that are not ok.
-__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool ok) {
-    uint64_t m = __ballot(ok);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t bal = __ballot(bit);
-        m &= bit ? bal : ~bal;
-    }
-    return ok ? m : 0ull;
-}
-
-// Exclusive scan over the NT threads' values (thread order); *total gets the sum.  All threads call it.
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *stmp /* NW + 1 */, uint32_t &total) {
+// Exclusive scan over the NT threads' values (thread order); total gets the sum.  All threads call it.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *stmp /* NW */, uint32_t &total) {
     const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
     uint32_t inc = v;
 #pragma unroll
@@ -226,48 +80,248 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *stmp /
     return base + inc - v;
 }
 
-// Pass 0 histogram, straight from the packed bases.  Also accumulates the number of valid windows per record
-// (the reference's total_count, src/libkmers.cpp:220-227) with one atomic per (wave round, record).
-__global__ __launch_bounds__(NT) void k_hist_bases(BasesArgs a, uint32_t *tilehist, uint32_t n_tiles, uint32_t *rec_total) {
-    __shared__ BasesLds L;
-    __shared__ uint32_t h[NW][RADIX];
-    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
-    const uint32_t tile = blockIdx.x;
-    for (uint32_t i = tid; i < NW * RADIX; i += NT) (&h[0][0])[i] = 0;
-    bases_tile_load(a, (uint64_t)tile * TILE, L, true);
-    for (int j = 0; j < IPT; ++j) {
-        const uint32_t o = w * WCHUNK + j * 64 + lane;
-        uint32_t key;
-        const bool ok = window_at(L, o, a.K, key);
-        const uint32_t rec = record_at(L, o);
-        if (ok) atomicAdd(&h[w][key & 255u], 1u);
-        // valid windows per record: lanes are position-ordered, so records form contiguous lane segments
-        const uint64_t okm = __ballot(ok);
-        if (okm) {
-            const uint32_t prev = __shfl_up(rec, 1);
-            const bool first = (lane == 0) || (rec != prev);
-            const uint64_t fm = __ballot(first);
-            if (first) {
-                const uint64_t above = (lane == 63) ? 0ull : (fm & ~((2ull << lane) - 1ull));
-                const uint32_t endl = above ? (uint32_t)__ffsll((long long)above) - 1u : 64u;
-                const uint64_t seg = ((endl == 64) ? ~0ull : ((1ull << endl) - 1ull)) & ~lanes_below(lane);
-                const uint32_t cnt = (uint32_t)__popcll(okm & seg);
-                if (cnt) atomicAdd(&rec_total[rec], cnt);
-            }
-        }
+// ------------------------------------------------------------------------------------------------------
+// Packed-bases tile: prefetch to registers, commit to LDS, window extraction, record lookup
+// ------------------------------------------------------------------------------------------------------
+
+struct BasesArgs {
+    const uint32_t *bases;
+    const uint32_t *valid;
+    const uint32_t *rec_flags;  // bit p set: a record starts at position p (built by k_mark_records); may be null (y)
+    const uint32_t *tile_cb;    // [n_tiles + 1]: record starts strictly before tile t's first position
+    uint64_t bases_words, valid_words;
+    uint64_t n_pos;
+    int K;
+};
+
+struct TileLds {
+    uint32_t sb[TILE / 16 + 2];   // 2-bit codes of the tile (+ overlap for windows that start near the end)
+    uint32_t sv[TILE / 32 + 2];   // validity bits
+    uint32_t sflag[TILE / 32];    // record-start bits
+    uint32_t spre[TILE / 64];     // record starts before 64-block b of the tile (exclusive prefix)
+    uint32_t cb;                  // record starts before the tile
+};
+
+struct TilePf {  // one tile's words, held in registers between fetch and commit
+    uint32_t b0, b1, v, f, cb;
+};
+
+template <bool WITH_REC>
+__device__ __forceinline__ TilePf tile_fetch(const BasesArgs &a, uint64_t tile) {
+    const uint32_t tid = threadIdx.x;
+    TilePf p;
+    const uint64_t bw = tile * (TILE / 16) + tid;
+    p.b0 = (bw < a.bases_words) ? a.bases[bw] : 0u;
+    p.b1 = 0u;
+    if (tid < 2) {
+        const uint64_t w2 = tile * (TILE / 16) + NT + tid;
+        p.b1 = (w2 < a.bases_words) ? a.bases[w2] : 0u;
+    }
+    const uint64_t vw = tile * (TILE / 32) + tid;
+    p.v = (tid < TILE / 32 + 2 && vw < a.valid_words) ? a.valid[vw] : 0u;
+    p.f = 0u;
+    p.cb = 0u;
+    if (WITH_REC) {
+        p.f = (tid < TILE / 32 && vw < a.valid_words) ? a.rec_flags[vw] : 0u;
+        p.cb = a.tile_cb[tile];
+    }
+    return p;
+}
+
+// All NT threads call it; ends with a barrier.
+template <bool WITH_REC>
+__device__ __forceinline__ void tile_commit(TileLds &L, const TilePf &p, uint32_t *stmp) {
+    const uint32_t tid = threadIdx.x;
+    L.sb[tid] = p.b0;
+    if (tid < 2) L.sb[NT + tid] = p.b1;
+    if (tid < TILE / 32 + 2) L.sv[tid] = p.v;
+    if (WITH_REC) {
+        if (tid < TILE / 32) L.sflag[tid] = p.f;
+        if (tid == 0) L.cb = p.cb;
+        // record starts per 64-position block: lanes 2b, 2b+1 hold its two flag words
+        const uint32_t pc = (tid < TILE / 32) ? (uint32_t)__popc(p.f) : 0u;
+        const uint32_t pair = pc + __shfl_xor(pc, 1);
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan((tid & 1) ? 0u : pair, stmp, tot);  // ends after a barrier
+        if (tid < TILE / 32 && !(tid & 1)) L.spre[tid >> 1] = ex;
     }
     __syncthreads();
-    if (tid < RADIX) {
-        uint32_t s = 0;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) s += h[i][tid];
-        tilehist[(uint64_t)tid * n_tiles + tile] = s;
+}
+
+// Window starting at tile offset o: true iff its K positions are all valid; key = the reference's k-mer id.
+__device__ __forceinline__ bool window_at(const TileLds &L, uint32_t o, int K, uint32_t &key) {
+    const uint32_t vi = o >> 5;
+    const u64 v = ((u64)L.sv[vi + 1] << 32) | L.sv[vi];
+    const uint32_t need = (1u << K) - 1u;  // K <= 16
+    const bool ok = ((uint32_t)(v >> (o & 31)) & need) == need;
+    const uint32_t bi = o >> 4;
+    const u64 x = ((u64)L.sb[bi] << 32) | L.sb[bi + 1];
+    const uint32_t sh = 64u - 2u * (o & 15) - 2u * (uint32_t)K;  // >= 2 for K <= 16
+    const uint32_t mask = (K == 16) ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
+    key = (uint32_t)(x >> sh) & mask;
+    return ok;
+}
+
+// Local record index (0-based inside this store) of tile offset o.
+__device__ __forceinline__ uint32_t record_at(const TileLds &L, uint32_t o) {
+    const uint32_t b = o >> 6, l = o & 63;
+    const u64 f = ((u64)L.sflag[2 * b + 1] << 32) | L.sflag[2 * b];
+    const u64 upto = (l == 63) ? ~0ull : ((2ull << l) - 1ull);  // bits 0..l
+    return L.cb + L.spre[b] + (uint32_t)__popcll(f & upto) - 1u;
+}
+
+// bit p of rec_flags := a record starts at p.  rec_flags is zeroed beforehand.
+__global__ void k_mark_records(const uint64_t *rec_start, uint64_t n_rec, uint32_t *rec_flags) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rec) return;
+    const uint64_t p = rec_start[r];
+    atomicOr(&rec_flags[p >> 5], 1u << (p & 31));
+}
+
+// tile_cb[t] = number of records that start strictly before position t*TILE, t in [0, n_tiles].
+__global__ void k_tile_cb(const uint64_t *rec_start, uint64_t n_rec, uint32_t n_tiles, uint32_t *tile_cb) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    const uint64_t target = t * TILE;
+    uint64_t lo = 0, hi = n_rec;  // first r with rec_start[r] >= target
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (rec_start[mid] < target)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    tile_cb[t] = (uint32_t)lo;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// y: dense histogram of valid windows
+// ------------------------------------------------------------------------------------------------------
+
+// Global atomics: int32 sums are order-independent, so the result is bit-exact whatever the interleaving.
+__global__ __launch_bounds__(NT) void k_count_y_global(BasesArgs a, int32_t *counts, uint64_t n_tiles) {
+    __shared__ TileLds L;
+    __shared__ uint32_t stmp[NW];
+    const uint32_t w = threadIdx.x >> 6, lane = lane_id();
+    uint64_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    TilePf pf = tile_fetch<false>(a, tile);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        tile_commit<false>(L, pf, stmp);
+        if (tile + gridDim.x < n_tiles) pf = tile_fetch<false>(a, tile + gridDim.x);
+#pragma unroll 4
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t o = w * WCHUNK + j * 64 + lane;
+            uint32_t key;
+            if (window_at(L, o, a.K, key)) atomicAdd(&counts[key], 1);
+        }
+        __syncthreads();
     }
 }
 
-// Later-pass histogram over stored keys.
-__global__ __launch_bounds__(NT) void k_hist_keys(const uint32_t *keys, const uint32_t *p_count, int shift, uint32_t *tilehist,
-                                                  uint32_t n_tiles) {
+// Tables of up to 32768 bins per sweep are privatised in LDS (u32 bins, no overflow) and flushed once per
+// workgroup: K <= 7 in one sweep; K = 8 in two sweeps over the tile range (bins [0,32768) then [32768,65536)):
+// the packed bases are 3 bits per position, so reading them twice costs far less than 4e8 contended global atomics.
+__global__ __launch_bounds__(NT) void k_count_y_lds(BasesArgs a, int32_t *counts, uint64_t n_tiles, uint32_t n_bins) {
+    __shared__ TileLds L;
+    __shared__ uint32_t stmp[NW];
+    __shared__ uint32_t h[32768];
+    const uint32_t w = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t sweep_bins = n_bins < 32768u ? n_bins : 32768u;
+    for (uint32_t lo = 0; lo < n_bins; lo += sweep_bins) {
+        for (uint32_t i = threadIdx.x; i < sweep_bins; i += NT) h[i] = 0;
+        __syncthreads();
+        uint64_t tile = blockIdx.x;
+        TilePf pf = tile_fetch<false>(a, tile < n_tiles ? tile : 0);
+        for (; tile < n_tiles; tile += gridDim.x) {
+            tile_commit<false>(L, pf, stmp);
+            if (tile + gridDim.x < n_tiles) pf = tile_fetch<false>(a, tile + gridDim.x);
+#pragma unroll 4
+            for (int j = 0; j < IPT; ++j) {
+                const uint32_t o = w * WCHUNK + j * 64 + lane;
+                uint32_t key;
+                if (window_at(L, o, a.K, key)) {
+                    const uint32_t b = key - lo;
+                    if (b < sweep_bins) atomicAdd(&h[b], 1u);
+                }
+            }
+            __syncthreads();
+        }
+        for (uint32_t i = threadIdx.x; i < sweep_bins; i += NT) {
+            const uint32_t v = h[i];
+            if (v) atomicAdd(&counts[lo + i], (int32_t)v);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// X pass structure: per-tile digit histogram -> exclusive scan -> stable scatter
+// ------------------------------------------------------------------------------------------------------
+
+// Lanes of the wave whose (ok, digit) equals this lane's; 0 for lanes that are not ok.
+__device__ __forceinline__ u64 match_digit(uint32_t d, bool ok) {
+    u64 m = __ballot(ok);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const u64 bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+    }
+    return ok ? m : 0ull;
+}
+
+// Pass 0 histogram, straight from the packed bases.  Also accumulates the number of valid windows per record
+// (the reference's total_count, src/libkmers.cpp:220-227) with one atomic per (wave round, record).
+__global__ __launch_bounds__(NT) void k_hist_bases(BasesArgs a, uint32_t *tilehist, uint32_t n_tiles, uint32_t *rec_total) {
+    __shared__ TileLds L;
+    __shared__ uint32_t stmp[NW];
+    __shared__ uint32_t h[NW][RADIX];
+    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
+    const uint32_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    if (t0 >= t1) return;
+    TilePf pf = tile_fetch<true>(a, t0);
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+        for (uint32_t i = tid; i < NW * RADIX; i += NT) (&h[0][0])[i] = 0;
+        tile_commit<true>(L, pf, stmp);
+        if (tile + 1 < t1) pf = tile_fetch<true>(a, tile + 1);
+#pragma unroll 2
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t o = w * WCHUNK + j * 64 + lane;
+            uint32_t key;
+            const bool ok = window_at(L, o, a.K, key);
+            if (ok) atomicAdd(&h[w][key & 255u], 1u);
+            // valid windows per record: lanes are position-ordered, so records form contiguous lane segments
+            const u64 okm = __ballot(ok);
+            if (okm) {
+                const uint32_t rec = record_at(L, o);
+                const uint32_t prev = __shfl_up(rec, 1);
+                const bool first = (lane == 0) || (rec != prev);
+                const u64 fm = __ballot(first);
+                if (first) {
+                    const u64 above = (lane == 63) ? 0ull : (fm & ~((2ull << lane) - 1ull));
+                    const uint32_t endl = above ? (uint32_t)__ffsll((long long)above) - 1u : 64u;
+                    const u64 seg = ((endl == 64) ? ~0ull : ((1ull << endl) - 1ull)) & ~lanes_below(lane);
+                    const uint32_t cnt = (uint32_t)__popcll(okm & seg);
+                    if (cnt) atomicAdd(&rec_total[rec], cnt);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < RADIX) {
+            uint32_t s = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) s += h[i][tid];
+            tilehist[(uint64_t)tid * n_tiles + tile] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// Later-pass histogram over stored entries.  One tile per workgroup; tiles past the entry count write zeros.
+__global__ __launch_bounds__(NT) void k_hist_entries(const u64 *ent, const uint32_t *p_count, int shift, uint32_t *tilehist,
+                                                     uint32_t n_tiles) {
     __shared__ uint32_t h[NW][RADIX];
     const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
     const uint32_t tile = blockIdx.x;
@@ -276,9 +330,16 @@ __global__ __launch_bounds__(NT) void k_hist_keys(const uint32_t *keys, const ui
     for (uint32_t i = tid; i < NW * RADIX; i += NT) (&h[0][0])[i] = 0;
     __syncthreads();
     if (base < E) {
+        u64 e[IPT];
+#pragma unroll
         for (int j = 0; j < IPT; ++j) {
             const uint64_t i = base + w * WCHUNK + j * 64 + lane;
-            if (i < E) atomicAdd(&h[w][(keys[i] >> shift) & 255u], 1u);
+            e[j] = (i < E) ? ent[i] : ~0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint64_t i = base + w * WCHUNK + j * 64 + lane;
+            if (i < E) atomicAdd(&h[w][(entry_key(e[j]) >> shift) & 255u], 1u);
         }
     }
     __syncthreads();
@@ -290,93 +351,119 @@ __global__ __launch_bounds__(NT) void k_hist_keys(const uint32_t *keys, const ui
     }
 }
 
-// Stable scatter of one tile by the 8-bit digit at `shift`.
-//   FROM_BASES: entries are generated from the packed store (pass 0); otherwise read from keys_in / cols_in.
-//   tilebase = exclusive scan of tilehist (digit-major), i.e. the global position of the first entry of
-//   (digit, tile).
+// Stable scatter by the 8-bit digit of the k-mer id at `shift`.  Persistent: workgroup b walks the contiguous tile
+// range [b*per, (b+1)*per) and fetches the next tile while the current one is ranked and written.
+//   FROM_BASES: entries are generated from the packed store (pass 0); otherwise read from `in`.
+//   tilebase = exclusive scan of the digit-major tile histogram: global position of the first entry of (digit, tile).
 template <bool FROM_BASES>
-__global__ __launch_bounds__(NT) void k_scatter(BasesArgs a, const uint32_t *keys_in, const uint32_t *cols_in,
-                                                const uint32_t *p_count, int shift, const uint32_t *tilebase, uint32_t n_tiles,
-                                                uint32_t *keys_out, uint32_t *cols_out) {
-    __shared__ uint32_t skey[TILE];
-    __shared__ uint32_t scol[TILE];
+__global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const u64 *in, const uint32_t *p_count, int shift,
+                                                   const uint32_t *tilebase, uint32_t n_tiles, u64 *out) {
+    __shared__ u64 sent[TILE];
     __shared__ uint32_t wcnt[NW][RADIX];
-    __shared__ uint32_t tstart[RADIX];   // first tile-local slot of each digit
-    __shared__ uint32_t gadj[RADIX];     // global base of (digit, tile) minus tstart[digit]
-    __shared__ uint32_t stmp[NW + 1];
-    __shared__ BasesLds L;               // only touched when FROM_BASES
+    __shared__ uint32_t tstart[RADIX];  // first tile-local slot of each digit
+    __shared__ uint32_t gadj[RADIX];    // global base of (digit, tile) minus tstart[digit]
+    __shared__ uint32_t stmp[NW];
+    __shared__ TileLds L;               // only touched when FROM_BASES
 
     const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
-    const uint32_t tile = blockIdx.x;
-    const uint64_t base = (uint64_t)tile * TILE;
-
-    uint32_t E = 0;
+    const int kshift = 32 + shift;
+    uint32_t E = 0, nt = n_tiles;
     if (!FROM_BASES) {
         E = *p_count;
-        if (base >= E) return;
+        nt = (uint32_t)(((uint64_t)E + TILE - 1) / TILE);
     }
-    for (uint32_t i = tid; i < NW * RADIX; i += NT) (&wcnt[0][0])[i] = 0;
-    if (FROM_BASES)
-        bases_tile_load(a, base, L, true);
-    else
-        __syncthreads();
+    const uint32_t per = (nt + gridDim.x - 1) / gridDim.x;
+    const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < nt) ? t0 + per : nt;
+    if (t0 >= t1) return;
 
-    uint32_t key[IPT], col[IPT], rank[IPT];
+    u64 e[IPT];
+    TilePf pf;
+    if (FROM_BASES) {
+        pf = tile_fetch<true>(a, t0);
+    } else {
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-        bool ok;
+        for (int j = 0; j < IPT; ++j) {
+            const uint64_t i = (uint64_t)t0 * TILE + w * WCHUNK + j * 64 + lane;
+            e[j] = (i < E) ? in[i] : 0ull;
+        }
+    }
+    uint32_t gb = (tid < RADIX) ? tilebase[(uint64_t)tid * n_tiles + t0] : 0u;
+
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+        const uint64_t base = (uint64_t)tile * TILE;
+        for (uint32_t i = tid; i < NW * RADIX; i += NT) (&wcnt[0][0])[i] = 0;
         if (FROM_BASES) {
-            const uint32_t o = w * WCHUNK + j * 64 + lane;
-            ok = window_at(L, o, a.K, key[j]);
-            col[j] = record_at(L, o);
+            tile_commit<true>(L, pf, stmp);
+            if (tile + 1 < t1) pf = tile_fetch<true>(a, tile + 1);
         } else {
-            const uint64_t i = base + w * WCHUNK + j * 64 + lane;
-            ok = i < E;
-            key[j] = ok ? keys_in[i] : 0u;
-            col[j] = ok ? cols_in[i] : 0u;
+            __syncthreads();
         }
-        const uint32_t d = (key[j] >> shift) & 255u;
-        const uint64_t m = match_digit(d, ok);
-        uint32_t before = 0;
-        if (ok) before = wcnt[w][d];
-        const uint32_t below = (uint32_t)__popcll(m & lanes_below(lane));
-        rank[j] = ok ? (before + below) : NONE;
-        if (ok && below == 0) wcnt[w][d] = before + (uint32_t)__popcll(m);  // the lowest lane of each group
-        asm volatile("" ::: "memory");  // next round must re-read wcnt
-    }
-    __syncthreads();
-    // digit d: exclusive scan of the per-wave counts over waves, then of the tile totals over digits
-    uint32_t dtot = 0;
-    if (tid < RADIX) {
+        // lane offset inside the tile, made opaque once per tile: otherwise the per-round LDS addresses and shift
+        // counts (loop-invariant across tiles) are hoisted out of the tile loop and spilled around it
+        uint32_t wl = w * WCHUNK + lane;
+        asm volatile("" : "+v"(wl));
+        uint32_t rank[IPT];
 #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const uint32_t t = wcnt[i][tid];
-            wcnt[i][tid] = dtot;
-            dtot += t;
+        for (int j = 0; j < IPT; ++j) {
+            bool ok;
+            if (FROM_BASES) {
+                const uint32_t o = wl + j * 64;
+                uint32_t key;
+                ok = window_at(L, o, a.K, key);
+                e[j] = make_entry(key, record_at(L, o));
+            } else {
+                ok = base + wl + j * 64 < E;
+            }
+            const uint32_t d = (uint32_t)(e[j] >> kshift) & 255u;
+            const u64 m = match_digit(d, ok);
+            uint32_t before = 0;
+            if (ok) before = wcnt[w][d];
+            const uint32_t below = (uint32_t)__popcll(m & lanes_below(lane));
+            rank[j] = ok ? (before + below) : NONE;
+            if (ok && below == 0) wcnt[w][d] = before + (uint32_t)__popcll(m);  // the lowest lane of each group
+            asm volatile("" ::: "memory");  // the next round must re-read wcnt
+            __builtin_amdgcn_sched_barrier(0);  // keep rounds apart: interleaving them only lengthens live ranges
         }
-    }
-    uint32_t tile_count;
-    const uint32_t dstart = block_excl_scan(dtot, stmp, tile_count);
-    if (tid < RADIX) {
-        tstart[tid] = dstart;
-        gadj[tid] = tilebase[(uint64_t)tid * n_tiles + tile] - dstart;
-    }
-    __syncthreads();
+        __syncthreads();
+        // digit d: exclusive scan of the per-wave counts over waves, then of the tile totals over digits
+        uint32_t dtot = 0;
+        if (tid < RADIX) {
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-        if (rank[j] != NONE) {
-            const uint32_t d = (key[j] >> shift) & 255u;
-            const uint32_t slot = tstart[d] + wcnt[w][d] + rank[j];
-            skey[slot] = key[j];
-            scol[slot] = col[j];
+            for (int i = 0; i < NW; ++i) {
+                const uint32_t t = wcnt[i][tid];
+                wcnt[i][tid] = dtot;
+                dtot += t;
+            }
         }
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < tile_count; i += NT) {
-        const uint32_t k = skey[i];
-        const uint32_t dst = gadj[(k >> shift) & 255u] + i;
-        keys_out[dst] = k;
-        cols_out[dst] = scol[i];
+        uint32_t tile_count;
+        const uint32_t dstart = block_excl_scan(dtot, stmp, tile_count);
+        if (tid < RADIX) {
+            tstart[tid] = dstart;
+            gadj[tid] = gb - dstart;
+            if (tile + 1 < t1) gb = tilebase[(uint64_t)tid * n_tiles + tile + 1];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            if (rank[j] != NONE) {
+                const uint32_t d = (uint32_t)(e[j] >> kshift) & 255u;
+                sent[tstart[d] + wcnt[w][d] + rank[j]] = e[j];
+            }
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!FROM_BASES && tile + 1 < t1) {  // e[] is free again: fetch the next tile behind the write-out
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) {
+                const uint64_t i = base + TILE + w * WCHUNK + j * 64 + lane;
+                e[j] = (i < E) ? in[i] : 0ull;
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < tile_count; i += NT) {
+            const u64 v = sent[i];
+            out[gadj[(uint32_t)(v >> kshift) & 255u] + i] = v;
+        }
+        __syncthreads();
     }
 }
 
@@ -388,7 +475,7 @@ constexpr int SCAN_IPT = 8;
 constexpr int SCAN_CHUNK = NT * SCAN_IPT;  // 4096 values per workgroup
 
 __global__ __launch_bounds__(NT) void k_scan_reduce(const uint32_t *in, uint64_t n, uint32_t *block_sums) {
-    __shared__ uint32_t stmp[NW + 1];
+    __shared__ uint32_t stmp[NW];
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_IPT;
     uint32_t s = 0;
 #pragma unroll
@@ -401,7 +488,7 @@ __global__ __launch_bounds__(NT) void k_scan_reduce(const uint32_t *in, uint64_t
 
 // One workgroup: exclusive scan of block_sums in place; grand total to *p_total.
 __global__ __launch_bounds__(NT) void k_scan_block_sums(uint32_t *block_sums, uint32_t n_blocks, uint32_t *p_total) {
-    __shared__ uint32_t stmp[NW + 1];
+    __shared__ uint32_t stmp[NW];
     uint32_t carry = 0;
     for (uint32_t base = 0; base < n_blocks; base += NT) {
         const uint32_t i = base + threadIdx.x;
@@ -415,7 +502,7 @@ __global__ __launch_bounds__(NT) void k_scan_block_sums(uint32_t *block_sums, ui
 }
 
 __global__ __launch_bounds__(NT) void k_scan_apply(const uint32_t *in, uint64_t n, const uint32_t *block_sums, uint32_t *out) {
-    __shared__ uint32_t stmp[NW + 1];
+    __shared__ uint32_t stmp[NW];
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_IPT;
     uint32_t v[SCAN_IPT];
     uint32_t s = 0;
@@ -434,49 +521,8 @@ __global__ __launch_bounds__(NT) void k_scan_apply(const uint32_t *in, uint64_t 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Run-length reduce of the sorted (k-mer, column) instances -> CSR
+// Run-length reduce of the sorted (k-mer, column) instances -> CSR, one kernel
 // ------------------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ bool is_head(const uint32_t *keys, const uint32_t *cols, uint64_t i, uint32_t E) {
-    if (i >= E) return false;
-    if (i == 0) return true;
-    return keys[i] != keys[i - 1] || cols[i] != cols[i - 1];
-}
-
-// Heads per tile and the first head of each tile.
-__global__ __launch_bounds__(NT) void k_rle_count(const uint32_t *keys, const uint32_t *cols, const uint32_t *p_count,
-                                                  uint32_t *tile_heads, uint32_t *first_head) {
-    __shared__ uint32_t s_cnt[NW], s_first[NW];
-    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
-    const uint32_t tile = blockIdx.x;
-    const uint32_t E = *p_count;
-    const uint64_t base = (uint64_t)tile * TILE;
-    uint32_t cnt = 0, first = NONE;
-    if (base < E) {
-        for (int j = 0; j < IPT; ++j) {
-            const uint64_t i = base + w * WCHUNK + j * 64 + lane;
-            const uint64_t hm = __ballot(is_head(keys, cols, i, E));
-            if (hm) {
-                if (first == NONE) first = (uint32_t)(base + w * WCHUNK + j * 64) + (uint32_t)__ffsll((long long)hm) - 1u;
-                cnt += (uint32_t)__popcll(hm);
-            }
-        }
-    }
-    if (lane == 0) {
-        s_cnt[w] = cnt;
-        s_first[w] = first;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t c = 0, f = NONE;
-        for (int i = 0; i < NW; ++i) {
-            c += s_cnt[i];
-            if (f == NONE) f = s_first[i];
-        }
-        tile_heads[tile] = c;
-        first_head[tile] = f;
-    }
-}
 
 struct FillTask {
     uint64_t begin, end, value;
@@ -501,78 +547,191 @@ __device__ __forceinline__ void fill_rows(uint64_t *row_ind, uint64_t lo, uint64
     }
 }
 
-// One CSR entry per head: column, value, and the row pointer entries of every row that starts (or is empty)
-// between the previous head's k-mer and this one.
-//   p_scalars[0] = E (instances), p_scalars[1] = nnz (heads)
-__global__ __launch_bounds__(NT) void k_rle_emit(const uint32_t *keys, const uint32_t *cols, const uint32_t *p_count,
-                                                 const uint32_t *p_nnz, const uint32_t *tile_headbase, const uint32_t *first_head,
-                                                 uint32_t n_tiles, const uint32_t *rec_total, uint64_t first_col, uint64_t M,
-                                                 uint64_t max_nz, float *data, uint64_t *col_ind, uint64_t *row_ind,
-                                                 FillTask *tasks, uint32_t *p_ntasks, uint32_t task_cap, uint32_t *p_err) {
-    __shared__ uint32_t sidx[TILE];
-    __shared__ uint32_t s_wave[NW];
-    __shared__ uint32_t s_next;
+// Chained scan across tiles ("decoupled look-back") of one number per tile, the tile's count of run heads.
+// status[t] = flag << 62 | value; flag 1: value = heads of tile t alone, flag 2: value = heads of tiles 0..t.
+// The whole state of a tile is ONE naturally aligned 8-byte word written by one relaxed agent-scope atomic store
+// and polled with relaxed agent-scope atomic loads (both bypass the non-coherent per-CU L1), so no fence is needed.
+// Tiles are numbered by an atomic ticket, so every predecessor of a tile has at least started and publishes its
+// flag-1 word without waiting for anything: the spin below always ends; it is bounded anyway (p_err on timeout).
+constexpr u64 ST_AGG = 1ull << 62, ST_PREFIX = 2ull << 62, ST_MASK = (1ull << 62) - 1ull;
+constexpr uint32_t SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ u64 st_load(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_store(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Called by wave 0 of tile `tile` (all 64 lanes).  Returns the number of heads in tiles 0..tile-1.
+__device__ __forceinline__ u64 lookback_exclusive(u64 *status, uint32_t tile, u64 mine, uint32_t *p_err) {
+    const uint32_t lane = lane_id();
+    if (tile == 0) {
+        if (lane == 0) st_store(&status[0], ST_PREFIX | mine);
+        return 0;
+    }
+    if (lane == 0) st_store(&status[tile], ST_AGG | mine);
+    u64 excl = 0;
+    int64_t hi = (int64_t)tile - 1;  // nearest predecessor not yet summed
+    uint32_t spins = 0;
+    while (hi >= 0) {
+        const int64_t t = hi - (int64_t)lane;
+        const u64 v = (t >= 0) ? st_load(&status[t]) : ST_PREFIX;  // before tile 0: an empty prefix
+        const u64 ready = __ballot((v >> 62) != 0);
+        const u64 pref = __ballot((v >> 62) == 2);
+        // usable lanes: from lane 0 up to the first PREFIX lane, all of which must be ready
+        const uint32_t stop = pref ? (uint32_t)__ffsll((long long)pref) - 1u : 63u;
+        const u64 need = (stop == 63) ? ~0ull : ((2ull << stop) - 1ull);
+        if ((ready & need) != need) {
+            if (++spins > SPIN_LIMIT) {
+                if (lane == 0) *p_err = 2u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+            continue;
+        }
+        u64 part = (lane <= stop) ? (v & ST_MASK) : 0ull;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+        excl += part;
+        if (pref) break;
+        hi -= 64;
+    }
+    if (lane == 0) st_store(&status[tile], ST_PREFIX | ((excl + mine) & ST_MASK));
+    return excl;
+}
+
+// One CSR entry per head (first instance of a (k-mer, column) run): column, value, and the row pointer entries of
+// every row that starts (or is empty) between the previous head's k-mer and this one.
+//   scal[0] = E (instances, input), scal[1] = nnz (output), scal[2] = ntasks, scal[3] = err, scal[5] = ticket
+__global__ __launch_bounds__(NT, 4) void k_rle(const u64 *ent, uint32_t *scal, u64 *status, const uint32_t *rec_total,
+                                               uint64_t first_col, uint64_t M, uint64_t max_nz, float *data, uint64_t *col_ind,
+                                               uint64_t *row_ind, FillTask *tasks, uint32_t task_cap) {
+    __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_cnt[NW], s_first[NW];
+    __shared__ uint32_t s_next;   // first head after this tile (index), E if none
+    __shared__ u64 s_out0;        // heads before this tile
     const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
-    const uint32_t tile = blockIdx.x;
-    const uint32_t E = *p_count;
-    const uint64_t nnz = *p_nnz;
-    if (nnz > max_nz) return;  // caller's buffers are too small: write nothing (host reports -2)
-    if (E == 0) {              // no instance at all: every row pointer is 0
+    uint32_t *p_nnz = &scal[1], *p_ntasks = &scal[2], *p_err = &scal[3];
+    const uint32_t E = scal[0];
+    if (tid == 0) s_tile = atomicAdd(&scal[5], 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    if (E == 0) {  // no instance at all: every row pointer is 0
         if (tile == 0 && tid == 0) fill_rows(row_ind, 0, M + 1, 0, tasks, p_ntasks, task_cap, p_err);
         return;
     }
     const uint64_t base = (uint64_t)tile * TILE;
     if (base >= E) return;
+    const uint32_t wbase_i = (uint32_t)base + w * WCHUNK;
 
-    uint64_t hm[IPT];
+    // ---- load, head flags
+    u64 e[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const uint64_t i = (uint64_t)wbase_i + j * 64 + lane;
+        e[j] = (i < E) ? ent[i] : ~0ull;
+    }
+    const u64 carry0 = (wbase_i > 0 && lane == 0) ? ent[wbase_i - 1] : 0ull;  // the entry before this wave's chunk
+    u64 carry = carry0;
+    u64 hm[IPT], rm[IPT];  // head lanes / heads that also start a new row (wave-uniform masks)
     uint32_t cnt = 0;
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
-        const uint64_t i = base + w * WCHUNK + j * 64 + lane;
-        hm[j] = __ballot(is_head(keys, cols, i, E));
+        const uint32_t i = wbase_i + j * 64 + lane;
+        u64 prev = __shfl_up(e[j], 1);
+        if (lane == 0) prev = carry;
+        const bool in = i < E;
+        const bool head = in && (i == 0 || e[j] != prev);
+        const bool rowh = head && (i == 0 || entry_key(e[j]) != entry_key(prev));
+        hm[j] = __ballot(head);
+        rm[j] = __ballot(rowh);
         cnt += (uint32_t)__popcll(hm[j]);
+        carry = __shfl(e[j], 63);  // lane 0 uses it next round
     }
-    if (lane == 0) s_wave[w] = cnt;
-    if (tid == 0) {  // first head after this tile (runs may span tiles)
-        uint32_t t = tile + 1;
-        while (t < n_tiles && first_head[t] == NONE) ++t;
-        s_next = (t < n_tiles) ? first_head[t] : E;
+    uint32_t first = NONE;
+#pragma unroll
+    for (int j = IPT - 1; j >= 0; --j)
+        if (hm[j]) first = wbase_i + j * 64 + (uint32_t)__ffsll((long long)hm[j]) - 1u;
+    if (lane == 0) {
+        s_cnt[w] = cnt;
+        s_first[w] = first;
+    }
+    // ---- the last run of the tile may go on in the following tiles: scan forward for the next head
+    if (w == NW - 1) {
+        const uint64_t tile_end = base + TILE;
+        uint32_t nxt = E;
+        if (tile_end < E) {
+            const u64 last = ent[tile_end - 1];
+            for (uint64_t p = tile_end; p < E; p += 64) {
+                const uint64_t i = p + lane;
+                const bool diff = (i < E) ? (ent[i] != last) : true;
+                const u64 dm = __ballot(diff);
+                if (dm) {
+                    const uint64_t at = p + (uint32_t)__ffsll((long long)dm) - 1u;
+                    nxt = (at < E) ? (uint32_t)at : E;
+                    break;
+                }
+            }
+        }
+        if (lane == 0) s_next = nxt;
     }
     __syncthreads();
-    uint32_t wbase = 0, n_heads = 0;
+    uint32_t wave_before = 0, n_heads = 0;
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-        const uint32_t t = s_wave[i];
-        if ((uint32_t)i < w) wbase += t;
+        const uint32_t t = s_cnt[i];
+        if ((uint32_t)i < w) wave_before += t;
         n_heads += t;
     }
-    uint32_t run = wbase;
-#pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-        if ((hm[j] >> lane) & 1ull)
-            sidx[run + (uint32_t)__popcll(hm[j] & lanes_below(lane))] = (uint32_t)(base + w * WCHUNK + j * 64 + lane);
-        run += (uint32_t)__popcll(hm[j]);
+    // ---- heads before this tile (chained scan), by wave 0
+    if (w == 0) {
+        const u64 ex = lookback_exclusive(status, tile, n_heads, p_err);
+        if (lane == 0) s_out0 = ex;
     }
     __syncthreads();
-    const uint64_t out0 = tile_headbase[tile];
-    for (uint32_t r = tid; r < n_heads; r += NT) {
-        const uint32_t i = sidx[r];
-        const uint32_t nxt = (r + 1 < n_heads) ? sidx[r + 1] : s_next;
-        const uint32_t k = keys[i], c = cols[i];
-        const uint64_t o = out0 + r;
-        // reference: float(count) / total_count with total_count uint32_t -> both rounded to float, float divide.
-        // Dividing the two floats in double and rounding once more is the correctly rounded float quotient
-        // (53 >= 2*24 + 2), independent of the device's float-division mode.
-        const float fc = (float)(nxt - i), ft = (float)rec_total[c];
-        data[o] = (float)((double)fc / (double)ft);
-        col_ind[o] = first_col + c;
-        if (i == 0) {
-            fill_rows(row_ind, 0, (uint64_t)k + 1, o, tasks, p_ntasks, task_cap, p_err);
-        } else {
-            const uint32_t pk = keys[i - 1];
-            if (pk != k) fill_rows(row_ind, (uint64_t)pk + 1, (uint64_t)k + 1, o, tasks, p_ntasks, task_cap, p_err);
+    const u64 out0 = s_out0;
+    // first head after this wave's chunk
+    uint32_t after = s_next;
+#pragma unroll
+    for (int i = NW - 1; i >= 1; --i)
+        if ((uint32_t)i > w && s_first[i] != NONE) after = s_first[i];
+
+    // ---- emit.  nxt_after = first head in rounds > j (wave-uniform), walked backwards
+    uint32_t nxt_after[IPT];
+    {
+        uint32_t nh = after;
+#pragma unroll
+        for (int j = IPT - 1; j >= 0; --j) {
+            nxt_after[j] = nh;
+            if (hm[j]) nh = wbase_i + j * 64 + (uint32_t)__ffsll((long long)hm[j]) - 1u;
         }
-        if (nxt == E) fill_rows(row_ind, (uint64_t)k + 1, M + 1, nnz, tasks, p_ntasks, task_cap, p_err);
+    }
+    uint32_t run = wave_before;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        if (hm[j] == 0) continue;  // wave-uniform
+        const uint32_t i = wbase_i + j * 64 + lane;
+        u64 prev = __shfl_up(e[j], 1);
+        const u64 prev0 = (j > 0) ? __shfl(e[j > 0 ? j - 1 : 0], 63) : carry0;
+        if (lane == 0) prev = prev0;
+        if ((hm[j] >> lane) & 1ull) {
+            const u64 above = (lane == 63) ? 0ull : (hm[j] >> (lane + 1));
+            const uint32_t nxt = above ? i + (uint32_t)__ffsll((long long)above) : nxt_after[j];
+            const u64 o = out0 + run + (uint32_t)__popcll(hm[j] & lanes_below(lane));
+            const uint32_t k = entry_key(e[j]), c = entry_col(e[j]);
+            if (o < max_nz) {
+                // reference: float(count) / total_count with total_count uint32_t: both operands are rounded to
+                // float, then one IEEE float division (hipcc's default float division is correctly rounded)
+                data[o] = (float)(nxt - i) / (float)rec_total[c];
+                col_ind[o] = first_col + c;
+            }
+            if ((rm[j] >> lane) & 1ull) {
+                const uint64_t lo = (i == 0) ? 0ull : (uint64_t)entry_key(prev) + 1;
+                fill_rows(row_ind, lo, (uint64_t)k + 1, o, tasks, p_ntasks, task_cap, p_err);
+            }
+            if (nxt == E) {  // the last head of all
+                *p_nnz = (uint32_t)(o + 1);
+                fill_rows(row_ind, (uint64_t)k + 1, M + 1, o + 1, tasks, p_ntasks, task_cap, p_err);
+            }
+        }
+        run += (uint32_t)__popcll(hm[j]);
     }
 }
 
@@ -655,8 +814,8 @@ struct XLayout {
     uint64_t hist_len;       // RADIX * n_tiles
     uint32_t scan_blocks;
     uint32_t task_cap;
-    size_t off_keyA, off_colA, off_keyB, off_colB, off_hist, off_blocksums, off_total, off_heads, off_first, off_scalars,
-        off_tasks, bytes;
+    size_t off_entA, off_entB, off_hist, off_blocksums, off_total, off_flags, off_tilecb, off_status, off_scalars, off_tasks,
+        bytes;
 };
 
 static XLayout x_layout(uint64_t n_pos, uint64_t n_rec, int K) {
@@ -677,15 +836,14 @@ static XLayout x_layout(uint64_t n_pos, uint64_t n_rec, int K) {
         o = align_up(o + bytes, 256);
         return at;
     };
-    l.off_keyA = take(emax * 4);
-    l.off_colA = take(emax * 4);
-    l.off_keyB = take(emax * 4);
-    l.off_colB = take(emax * 4);
+    l.off_entA = take(emax * 8);
+    l.off_entB = take(emax * 8);
     l.off_hist = take(l.hist_len * 4);
     l.off_blocksums = take((size_t)l.scan_blocks * 4 + 4);
     l.off_total = take((n_rec ? n_rec : 1) * 4);
-    l.off_heads = take((size_t)l.n_tiles * 4 + 4);
-    l.off_first = take((size_t)l.n_tiles * 4 + 4);
+    l.off_flags = take(((emax + 31) / 32 + 4) * 4);
+    l.off_tilecb = take(((size_t)l.n_tiles + 2) * 4);
+    l.off_status = take(((size_t)l.n_tiles + 1) * 8);
     l.off_scalars = take(64);
     l.off_tasks = take((size_t)l.task_cap * sizeof(FillTask));
     l.bytes = o;
@@ -715,14 +873,14 @@ static int scan_u32(const uint32_t *in, uint64_t n, uint32_t *out, uint32_t *blo
 int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words, uint64_t n_pos, int K,
             int32_t *d_counts, hipStream_t s) {
     if (n_pos == 0) return 0;
-    BasesArgs a{d_bases, d_valid, nullptr, bases_words, valid_words, n_pos, 0, K};
+    BasesArgs a{d_bases, d_valid, nullptr, nullptr, bases_words, valid_words, n_pos, K};
     const uint64_t n_tiles = (n_pos + TILE - 1) / TILE;
-    const uint32_t n_bins = 1u << (2 * (K > 7 ? 7 : K));
-    if (K <= 7) {
-        const uint32_t grid = (uint32_t)(n_tiles < 512 ? n_tiles : 512);
+    if (K <= 8) {
+        const uint32_t n_bins = 1u << (2 * K);
+        const uint32_t grid = (uint32_t)(n_tiles < 256 ? n_tiles : 256);  // 128 KiB of LDS: one workgroup per CU
         hipLaunchKernelGGL(k_count_y_lds, dim3(grid), dim3(NT), 0, s, a, d_counts, n_tiles, n_bins);
     } else {
-        const uint32_t grid = (uint32_t)(n_tiles < 4096 ? n_tiles : 4096);
+        const uint32_t grid = (uint32_t)(n_tiles < 2048 ? n_tiles : 2048);
         hipLaunchKernelGGL(k_count_y_global, dim3(grid), dim3(NT), 0, s, a, d_counts, n_tiles);
     }
     KK_CHECK(hipGetLastError());
@@ -736,12 +894,12 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     if (ws_bytes < l.bytes) return -14;
     const uint64_t M = 1ull << (2 * K);
     char *ws = (char *)d_ws;
-    uint32_t *keyA = (uint32_t *)(ws + l.off_keyA), *colA = (uint32_t *)(ws + l.off_colA);
-    uint32_t *keyB = (uint32_t *)(ws + l.off_keyB), *colB = (uint32_t *)(ws + l.off_colB);
+    u64 *entA = (u64 *)(ws + l.off_entA), *entB = (u64 *)(ws + l.off_entB);
     uint32_t *hist = (uint32_t *)(ws + l.off_hist), *bsum = (uint32_t *)(ws + l.off_blocksums);
     uint32_t *total = (uint32_t *)(ws + l.off_total);
-    uint32_t *heads = (uint32_t *)(ws + l.off_heads), *first = (uint32_t *)(ws + l.off_first);
-    uint32_t *scal = (uint32_t *)(ws + l.off_scalars);  // [0]=E [1]=nnz [2]=ntasks [3]=err
+    uint32_t *flags = (uint32_t *)(ws + l.off_flags), *tilecb = (uint32_t *)(ws + l.off_tilecb);
+    u64 *status = (u64 *)(ws + l.off_status);
+    uint32_t *scal = (uint32_t *)(ws + l.off_scalars);  // [0]=E [1]=nnz [2]=ntasks [3]=err [4]=dummy [5]=ticket
     FillTask *tasks = (FillTask *)(ws + l.off_tasks);
 
     PhaseTimer pt(s);
@@ -752,49 +910,47 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         *nnz_out = 0;
         return 0;
     }
+    const size_t flag_words = (size_t)((n_pos + 31) / 32 + 4);
     KK_CHECK(hipMemsetAsync(total, 0, n_rec * 4, s));
+    KK_CHECK(hipMemsetAsync(flags, 0, flag_words * 4, s));
+    KK_CHECK(hipMemsetAsync(status, 0, ((size_t)l.n_tiles + 1) * 8, s));
+    hipLaunchKernelGGL(k_mark_records, dim3((uint32_t)((n_rec + 255) / 256)), dim3(256), 0, s, d_rec_start, n_rec, flags);
+    hipLaunchKernelGGL(k_tile_cb, dim3((l.n_tiles + 1 + 255) / 256), dim3(256), 0, s, d_rec_start, n_rec, l.n_tiles, tilecb);
+    pt.mark("setup");
 
-    BasesArgs a{d_bases, d_valid, d_rec_start, bases_words, valid_words, n_pos, n_rec, K};
+    // rec_flags is indexed like valid[] (one bit per position), so it shares valid's word bound
+    const uint64_t vw = valid_words < flag_words ? valid_words : flag_words;
+    BasesArgs a{d_bases, d_valid, flags, tilecb, bases_words, vw, n_pos, K};
     const dim3 grid(l.n_tiles), block(NT);
+    const dim3 pgrid(l.n_tiles < (uint32_t)PERSIST_BLOCKS ? l.n_tiles : (uint32_t)PERSIST_BLOCKS);
+    const dim3 hgrid(l.n_tiles < 2048u ? l.n_tiles : 2048u);
     const int n_pass = (2 * K + 7) / 8;
 
     // pass 0: packed bases -> (key, col) instances partitioned by the lowest digit
-    pt.mark("memset");
-    hipLaunchKernelGGL(k_hist_bases, grid, block, 0, s, a, hist, l.n_tiles, total);
+    hipLaunchKernelGGL(k_hist_bases, hgrid, block, 0, s, a, hist, l.n_tiles, total);
     pt.mark("k_hist_bases");
     if (int rc = scan_u32(hist, l.hist_len, hist, bsum, l.scan_blocks, &scal[0], s)) return rc;
     pt.mark("k_scan");
-    hipLaunchKernelGGL(k_scatter<true>, grid, block, 0, s, a, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
-                       (const uint32_t *)&scal[0], 0, (const uint32_t *)hist, l.n_tiles, keyA, colA);
+    hipLaunchKernelGGL(k_scatter<true>, pgrid, block, 0, s, a, (const u64 *)nullptr, (const uint32_t *)&scal[0], 0,
+                       (const uint32_t *)hist, l.n_tiles, entA);
     pt.mark("k_scatter<bases>");
-    uint32_t *ki = keyA, *ci = colA, *ko = keyB, *co = colB;
+    u64 *ei = entA, *eo = entB;
     for (int p = 1; p < n_pass; ++p) {
         const int shift = 8 * p;
-        hipLaunchKernelGGL(k_hist_keys, grid, block, 0, s, (const uint32_t *)ki, (const uint32_t *)&scal[0], shift, hist, l.n_tiles);
-        pt.mark("k_hist_keys");
+        hipLaunchKernelGGL(k_hist_entries, grid, block, 0, s, (const u64 *)ei, (const uint32_t *)&scal[0], shift, hist, l.n_tiles);
+        pt.mark("k_hist_entries");
         if (int rc = scan_u32(hist, l.hist_len, hist, bsum, l.scan_blocks, &scal[4], s)) return rc;
         pt.mark("k_scan");
-        hipLaunchKernelGGL(k_scatter<false>, grid, block, 0, s, a, (const uint32_t *)ki, (const uint32_t *)ci,
-                           (const uint32_t *)&scal[0], shift, (const uint32_t *)hist, l.n_tiles, ko, co);
-        pt.mark("k_scatter<keys>");
-        uint32_t *t;
-        t = ki, ki = ko, ko = t;
-        t = ci, ci = co, co = t;
+        hipLaunchKernelGGL(k_scatter<false>, pgrid, block, 0, s, a, (const u64 *)ei, (const uint32_t *)&scal[0], shift,
+                           (const uint32_t *)hist, l.n_tiles, eo);
+        pt.mark("k_scatter<entries>");
+        u64 *t = ei;
+        ei = eo, eo = t;
     }
-    // run-length reduce
-    hipLaunchKernelGGL(k_rle_count, grid, block, 0, s, (const uint32_t *)ki, (const uint32_t *)ci, (const uint32_t *)&scal[0], heads,
-                       first);
-    pt.mark("k_rle_count");
-    {
-        const uint32_t nb = (l.n_tiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
-        if (int rc = scan_u32(heads, l.n_tiles, heads, bsum, nb, &scal[1], s)) return rc;
-    }
-    pt.mark("k_scan");
-    hipLaunchKernelGGL(k_rle_emit, grid, block, 0, s, (const uint32_t *)ki, (const uint32_t *)ci, (const uint32_t *)&scal[0],
-                       (const uint32_t *)&scal[1], (const uint32_t *)heads, (const uint32_t *)first, l.n_tiles,
-                       (const uint32_t *)total, first_col, M, max_nz, d_data, d_col_ind, d_row_ind, tasks, &scal[2], l.task_cap,
-                       &scal[3]);
-    pt.mark("k_rle_emit");
+    // run-length reduce -> CSR
+    hipLaunchKernelGGL(k_rle, grid, block, 0, s, (const u64 *)ei, scal, status, (const uint32_t *)total, first_col, M, max_nz,
+                       d_data, d_col_ind, d_row_ind, tasks, l.task_cap);
+    pt.mark("k_rle");
     hipLaunchKernelGGL(k_fill_tasks, dim3(2048), block, 0, s, d_row_ind, (const FillTask *)tasks, (const uint32_t *)&scal[2],
                        l.task_cap);
     pt.mark("k_fill_tasks");
@@ -804,11 +960,11 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     KK_CHECK(hipStreamSynchronize(s));
     pt.finish();
     *nnz_out = h[1];
-    if ((uint64_t)h[1] > max_nz) return -2;
     if (h[3]) {
-        fprintf(stderr, "libkmers: internal error: row-pointer fill queue overflow\n");
+        fprintf(stderr, "libkmers: internal error %u in the CSR emit (1: row-pointer fill queue overflow, 2: scan timeout)\n", h[3]);
         return -11;
     }
+    if ((uint64_t)h[1] > max_nz) return -2;
     return 0;
 }
 
