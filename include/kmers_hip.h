@@ -108,6 +108,10 @@ void kmers_hip_profile_enable(int on);
 int kmers_hip_profile_count(void);
 int kmers_hip_profile_get(int i, char *name, size_t name_cap, double *ms_total, uint64_t *calls);
 
+/* Diagnostic builds only (`python -m kmers_amd.build --stamps`, -DKK_STAMPS): cycle sums of the phases of the two
+ * partition kernels (s_memtime, wave 0 of every workgroup).  The product build returns KMERS_ERR_BAD_ARG. */
+int kmers_hip_debug_stamps(unsigned long long *out16, int reset);
+
 /* ---- host-side merge of per-shard CSRs (multi-GPU X) --------------------------- */
 
 /* Interleave n_parts CSR matrices that cover disjoint ascending column ranges (part g's columns all below

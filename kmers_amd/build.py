@@ -29,21 +29,27 @@ def up_to_date():
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile kmers_amd/lib/libkmers.so for gfx950.  Cross-compiles without a GPU."""
-    if not force and up_to_date():
-        return LIB
+def build(force=False, verbose=False, stamps=False):
+    """Compile kmers_amd/lib/libkmers.so for gfx950.  Cross-compiles without a GPU.
+    stamps=True builds the diagnostic variant lib/libkmers_stamps.so (in-kernel phase timers; never the product)."""
+    if stamps:
+        out = os.path.join(LIB_DIR, "libkmers_stamps.so")
+    else:
+        out = LIB
+        if not force and up_to_date():
+            return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB]
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out]
+    if stamps:
+        cmd.append("-DKK_STAMPS")
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-lz", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
-    print(LIB)
+    print(build(force="--force" in sys.argv, verbose=True, stamps="--stamps" in sys.argv))

@@ -51,11 +51,45 @@ static_assert(TILE % 64 == 0, "tile must be a whole number of wave rounds");
 
 typedef unsigned long long u64;
 
+// Diagnostic build only (-DKK_STAMPS): per-phase cycle sums of the scatter kernels, wave 0 lane 0 of every workgroup.
+#ifdef KK_STAMPS
+__device__ int g_ablate;   // diagnostic: 1 = no write-out stores, 2 = no entry prefetch loads, 4 = no ranking
+#define KK_ABLATE(bit) (g_ablate & (bit))
+__device__ u64 g_stamps[16];
+#define KK_STAMP(k)                                                         \
+    do {                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        if (threadIdx.x == 0) {                                             \
+            const u64 now_ = __builtin_amdgcn_s_memtime();                  \
+            stamp_acc_[k] += now_ - stamp_last_;                            \
+            stamp_last_ = now_;                                             \
+        }                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+    } while (0)
+#define KK_STAMP_BEGIN()  u64 stamp_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u64 stamp_last_ = __builtin_amdgcn_s_memtime()
+#define KK_STAMP_END(off)                                                                        \
+    do {                                                                                         \
+        if (threadIdx.x == 0)                                                                    \
+            for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&g_stamps[(off) + q_], stamp_acc_[q_]);    \
+    } while (0)
+#else
+#define KK_ABLATE(bit) 0
+#define KK_STAMP(k) do {} while (0)
+#define KK_STAMP_BEGIN() do {} while (0)
+#define KK_STAMP_END(off) do {} while (0)
+#endif
+
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 __device__ __forceinline__ u64 lanes_below(uint32_t lane) { return (1ull << lane) - 1ull; }
 __device__ __forceinline__ u64 make_entry(uint32_t key, uint32_t col) { return ((u64)key << 32) | col; }
 __device__ __forceinline__ uint32_t entry_key(u64 e) { return (uint32_t)(e >> 32); }
 __device__ __forceinline__ uint32_t entry_col(u64 e) { return (uint32_t)e; }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release/acquire fence around
+// s_barrier, and on gfx950 global loads, stores and LDS ops are released by s_waitcnt vmcnt(0) / lgkmcnt(0): it would
+// drain every global prefetch and every write-out store at each barrier.  No kernel here passes GLOBAL data between
+// the waves of a workgroup, so waiting for this wave's LDS operations before the barrier is all that is needed.
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Exclusive scan over the NT threads' values (thread order); total gets the sum.  All threads call it.
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *stmp /* NW */, uint32_t &total) {
@@ -66,9 +100,9 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *stmp /
         const uint32_t t = __shfl_up(inc, d);
         if (lane >= (uint32_t)d) inc += t;
     }
-    __syncthreads();  // stmp may still be read from a previous call
+    lds_sync();  // stmp may still be read from a previous call
     if (lane == 63) stmp[w] = inc;
-    __syncthreads();
+    lds_sync();
     uint32_t base = 0, tot = 0;
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
@@ -145,7 +179,7 @@ __device__ __forceinline__ void tile_commit(TileLds &L, const TilePf &p, uint32_
         const uint32_t ex = block_excl_scan((tid & 1) ? 0u : pair, stmp, tot);  // ends after a barrier
         if (tid < TILE / 32 && !(tid & 1)) L.spre[tid >> 1] = ex;
     }
-    __syncthreads();
+    lds_sync();
 }
 
 // Window starting at tile offset o: true iff its K positions are all valid; key = the reference's k-mer id.
@@ -215,7 +249,7 @@ __global__ __launch_bounds__(NT) void k_count_y_global(BasesArgs a, int32_t *cou
             uint32_t key;
             if (window_at(L, o, a.K, key)) atomicAdd(&counts[key], 1);
         }
-        __syncthreads();
+        lds_sync();
     }
 }
 
@@ -230,7 +264,7 @@ __global__ __launch_bounds__(NT) void k_count_y_lds(BasesArgs a, int32_t *counts
     const uint32_t sweep_bins = n_bins < 32768u ? n_bins : 32768u;
     for (uint32_t lo = 0; lo < n_bins; lo += sweep_bins) {
         for (uint32_t i = threadIdx.x; i < sweep_bins; i += NT) h[i] = 0;
-        __syncthreads();
+        lds_sync();
         uint64_t tile = blockIdx.x;
         TilePf pf = tile_fetch<false>(a, tile < n_tiles ? tile : 0);
         for (; tile < n_tiles; tile += gridDim.x) {
@@ -245,13 +279,13 @@ __global__ __launch_bounds__(NT) void k_count_y_lds(BasesArgs a, int32_t *counts
                     if (b < sweep_bins) atomicAdd(&h[b], 1u);
                 }
             }
-            __syncthreads();
+            lds_sync();
         }
         for (uint32_t i = threadIdx.x; i < sweep_bins; i += NT) {
             const uint32_t v = h[i];
             if (v) atomicAdd(&counts[lo + i], (int32_t)v);
         }
-        __syncthreads();
+        lds_sync();
     }
 }
 
@@ -259,16 +293,20 @@ __global__ __launch_bounds__(NT) void k_count_y_lds(BasesArgs a, int32_t *counts
 // X pass structure: per-tile digit histogram -> exclusive scan -> stable scatter
 // ------------------------------------------------------------------------------------------------------
 
-// Lanes of the wave whose (ok, digit) equals this lane's; 0 for lanes that are not ok.
-__device__ __forceinline__ u64 match_digit(uint32_t d, bool ok) {
-    u64 m = __ballot(ok);
+// Lanes of the wave that are ok and hold the same 8-bit digit as this lane (garbage for lanes that are not ok).
+// Per bit: t = 0 / ~0 from the lane's own bit (v_bfe_i32), one ballot (v_cmp), and "lanes that differ from me on this
+// bit" = ballot ^ t folded into the running mask with two 32-bit ops per half: 6 VALU per bit.
+__device__ __forceinline__ void match_digit(uint32_t d, u64 okm, uint32_t &m_lo, uint32_t &m_hi) {
+    uint32_t dl = 0, dh = 0;
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const u64 bal = __ballot(bit);
-        m &= bit ? bal : ~bal;
+        const uint32_t t = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);
+        const u64 bal = __ballot(t != 0);
+        dl |= (uint32_t)bal ^ t;
+        dh |= (uint32_t)(bal >> 32) ^ t;
     }
-    return ok ? m : 0ull;
+    m_lo = ~dl & (uint32_t)okm;
+    m_hi = ~dh & (uint32_t)(okm >> 32);
 }
 
 // Pass 0 histogram, straight from the packed bases.  Also accumulates the number of valid windows per record
@@ -308,14 +346,14 @@ __global__ __launch_bounds__(NT) void k_hist_bases(BasesArgs a, uint32_t *tilehi
                 }
             }
         }
-        __syncthreads();
+        lds_sync();
         if (tid < RADIX) {
             uint32_t s = 0;
 #pragma unroll
             for (int i = 0; i < NW; ++i) s += h[i][tid];
             tilehist[(uint64_t)tid * n_tiles + tile] = s;
         }
-        __syncthreads();
+        lds_sync();
     }
 }
 
@@ -328,7 +366,7 @@ __global__ __launch_bounds__(NT) void k_hist_entries(const u64 *ent, const uint3
     const uint32_t E = *p_count;
     const uint64_t base = (uint64_t)tile * TILE;
     for (uint32_t i = tid; i < NW * RADIX; i += NT) (&h[0][0])[i] = 0;
-    __syncthreads();
+    lds_sync();
     if (base < E) {
         u64 e[IPT];
 #pragma unroll
@@ -342,7 +380,7 @@ __global__ __launch_bounds__(NT) void k_hist_entries(const u64 *ent, const uint3
             if (i < E) atomicAdd(&h[w][(entry_key(e[j]) >> shift) & 255u], 1u);
         }
     }
-    __syncthreads();
+    lds_sync();
     if (tid < RADIX) {
         uint32_t s = 0;
 #pragma unroll
@@ -360,13 +398,11 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const u64 *in, c
                                                    const uint32_t *tilebase, uint32_t n_tiles, u64 *out) {
     __shared__ u64 sent[TILE];
     __shared__ uint32_t wcnt[NW][RADIX];
-    __shared__ uint32_t tstart[RADIX];  // first tile-local slot of each digit
     __shared__ uint32_t gadj[RADIX];    // global base of (digit, tile) minus tstart[digit]
     __shared__ uint32_t stmp[NW];
     __shared__ TileLds L;               // only touched when FROM_BASES
 
     const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
-    const int kshift = 32 + shift;
     uint32_t E = 0, nt = n_tiles;
     if (!FROM_BASES) {
         E = *p_count;
@@ -389,6 +425,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const u64 *in, c
     }
     uint32_t gb = (tid < RADIX) ? tilebase[(uint64_t)tid * n_tiles + t0] : 0u;
 
+    KK_STAMP_BEGIN();
     for (uint32_t tile = t0; tile < t1; ++tile) {
         const uint64_t base = (uint64_t)tile * TILE;
         for (uint32_t i = tid; i < NW * RADIX; i += NT) (&wcnt[0][0])[i] = 0;
@@ -396,12 +433,15 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const u64 *in, c
             tile_commit<true>(L, pf, stmp);
             if (tile + 1 < t1) pf = tile_fetch<true>(a, tile + 1);
         } else {
-            __syncthreads();
+            lds_sync();
         }
         // lane offset inside the tile, made opaque once per tile: otherwise the per-round LDS addresses and shift
         // counts (loop-invariant across tiles) are hoisted out of the tile loop and spilled around it
         uint32_t wl = w * WCHUNK + lane;
         asm volatile("" : "+v"(wl));
+        KK_STAMP(0);  // zero + commit/barrier
+        const uint32_t n_valid = FROM_BASES ? (uint32_t)TILE : (uint32_t)((E - base < TILE) ? E - base : TILE);
+        uint32_t *const wrow = &wcnt[w][0];
         uint32_t rank[IPT];
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
@@ -410,61 +450,78 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const u64 *in, c
                 const uint32_t o = wl + j * 64;
                 uint32_t key;
                 ok = window_at(L, o, a.K, key);
-                e[j] = make_entry(key, record_at(L, o));
+                uint32_t col = record_at(L, o);
+                asm volatile("" : "+v"(col));  // finish the column now: sunk to its use it keeps 4 LDS words per round alive
+                e[j] = make_entry(key, col);
             } else {
-                ok = base + wl + j * 64 < E;
+                ok = wl + j * 64 < n_valid;
             }
-            const uint32_t d = (uint32_t)(e[j] >> kshift) & 255u;
-            const u64 m = match_digit(d, ok);
+            const uint32_t d = __builtin_amdgcn_ubfe(entry_key(e[j]), (uint32_t)shift, 8u);
+            uint32_t m_lo, m_hi;
+            if (KK_ABLATE(4)) {
+                m_lo = ok ? (1u << (lane & 31)) : 0u, m_hi = 0;
+            } else
+                match_digit(d, __ballot(ok), m_lo, m_hi);
             uint32_t before = 0;
-            if (ok) before = wcnt[w][d];
-            const uint32_t below = (uint32_t)__popcll(m & lanes_below(lane));
+            if (ok) before = wrow[d];
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
             rank[j] = ok ? (before + below) : NONE;
-            if (ok && below == 0) wcnt[w][d] = before + (uint32_t)__popcll(m);  // the lowest lane of each group
+            if (ok && below == 0) wrow[d] = before + (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);  // lowest lane of the group
             asm volatile("" ::: "memory");  // the next round must re-read wcnt
             __builtin_amdgcn_sched_barrier(0);  // keep rounds apart: interleaving them only lengthens live ranges
         }
-        __syncthreads();
-        // digit d: exclusive scan of the per-wave counts over waves, then of the tile totals over digits
+        KK_STAMP(1);  // ranking rounds (wave 0)
+        lds_sync();
+        KK_STAMP(2);  // barrier after ranking
+        // digit d: exclusive scan of the per-wave counts over waves, then of the tile totals over digits;
+        // afterwards wcnt[w][d] = tile-local slot of the first entry of (wave w, digit d)
         uint32_t dtot = 0;
+        uint32_t wc[NW];
         if (tid < RADIX) {
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
-                const uint32_t t = wcnt[i][tid];
-                wcnt[i][tid] = dtot;
-                dtot += t;
+                wc[i] = dtot;
+                dtot += wcnt[i][tid];
             }
         }
         uint32_t tile_count;
         const uint32_t dstart = block_excl_scan(dtot, stmp, tile_count);
         if (tid < RADIX) {
-            tstart[tid] = dstart;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) wcnt[i][tid] = dstart + wc[i];
             gadj[tid] = gb - dstart;
             if (tile + 1 < t1) gb = tilebase[(uint64_t)tid * n_tiles + tile + 1];
         }
-        __syncthreads();
+        lds_sync();
+        KK_STAMP(3);  // digit scan
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             if (rank[j] != NONE) {
-                const uint32_t d = (uint32_t)(e[j] >> kshift) & 255u;
-                sent[tstart[d] + wcnt[w][d] + rank[j]] = e[j];
+                const uint32_t d = __builtin_amdgcn_ubfe(entry_key(e[j]), (uint32_t)shift, 8u);
+                sent[wrow[d] + rank[j]] = e[j];
             }
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-        if (!FROM_BASES && tile + 1 < t1) {  // e[] is free again: fetch the next tile behind the write-out
+        if (!FROM_BASES && tile + 1 < t1 && !KK_ABLATE(2)) {  // e[] is free again: fetch the next tile behind the write-out
 #pragma unroll
             for (int j = 0; j < IPT; ++j) {
                 const uint64_t i = base + TILE + w * WCHUNK + j * 64 + lane;
                 e[j] = (i < E) ? in[i] : 0ull;
             }
         }
-        __syncthreads();
+        KK_STAMP(4);  // LDS scatter + prefetch issue
+        lds_sync();
+        KK_STAMP(5);  // barrier
         for (uint32_t i = tid; i < tile_count; i += NT) {
             const u64 v = sent[i];
-            out[gadj[(uint32_t)(v >> kshift) & 255u] + i] = v;
+            const uint32_t dst = gadj[__builtin_amdgcn_ubfe(entry_key(v), (uint32_t)shift, 8u)] + i;
+            if (!KK_ABLATE(1) || v == 0x123456789abcdefull) out[dst] = v;
         }
-        __syncthreads();
+        KK_STAMP(6);  // write-out
+        lds_sync();
+        KK_STAMP(7);  // end barrier
     }
+    KK_STAMP_END(FROM_BASES ? 0 : 8);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -611,7 +668,7 @@ __global__ __launch_bounds__(NT, 4) void k_rle(const u64 *ent, uint32_t *scal, u
     uint32_t *p_nnz = &scal[1], *p_ntasks = &scal[2], *p_err = &scal[3];
     const uint32_t E = scal[0];
     if (tid == 0) s_tile = atomicAdd(&scal[5], 1u);
-    __syncthreads();
+    lds_sync();
     const uint32_t tile = s_tile;
     if (E == 0) {  // no instance at all: every row pointer is 0
         if (tile == 0 && tid == 0) fill_rows(row_ind, 0, M + 1, 0, tasks, p_ntasks, task_cap, p_err);
@@ -653,26 +710,35 @@ __global__ __launch_bounds__(NT, 4) void k_rle(const u64 *ent, uint32_t *scal, u
         s_cnt[w] = cnt;
         s_first[w] = first;
     }
-    // ---- the last run of the tile may go on in the following tiles: scan forward for the next head
+    // ---- the last run of the tile may go on in the following tiles: find the next head after the tile.
+    // The array is sorted as 64-bit values (k-mer id major, column minor), so that head is the first entry greater
+    // than the tile's last one: one 64-entry probe (the common case), then a binary search -- O(log E) even when one
+    // run spans the rest of the array (a single poly-A record of any length).
     if (w == NW - 1) {
         const uint64_t tile_end = base + TILE;
         uint32_t nxt = E;
         if (tile_end < E) {
             const u64 last = ent[tile_end - 1];
-            for (uint64_t p = tile_end; p < E; p += 64) {
-                const uint64_t i = p + lane;
-                const bool diff = (i < E) ? (ent[i] != last) : true;
-                const u64 dm = __ballot(diff);
-                if (dm) {
-                    const uint64_t at = p + (uint32_t)__ffsll((long long)dm) - 1u;
-                    nxt = (at < E) ? (uint32_t)at : E;
-                    break;
+            const uint64_t i = tile_end + lane;
+            const u64 dm = __ballot((i < E) ? (ent[i] != last) : true);
+            if (dm) {
+                const uint64_t at = tile_end + (uint32_t)__ffsll((long long)dm) - 1u;
+                nxt = (at < E) ? (uint32_t)at : E;
+            } else {
+                uint64_t lo = tile_end + 64, hi = E;  // first index in [lo, hi] whose entry is > last
+                while (lo < hi) {
+                    const uint64_t mid = (lo + hi) >> 1;
+                    if (ent[mid] > last)
+                        hi = mid;
+                    else
+                        lo = mid + 1;
                 }
+                nxt = (uint32_t)lo;
             }
         }
         if (lane == 0) s_next = nxt;
     }
-    __syncthreads();
+    lds_sync();
     uint32_t wave_before = 0, n_heads = 0;
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
@@ -685,7 +751,7 @@ __global__ __launch_bounds__(NT, 4) void k_rle(const u64 *ent, uint32_t *scal, u
         const u64 ex = lookback_exclusive(status, tile, n_heads, p_err);
         if (lane == 0) s_out0 = ex;
     }
-    __syncthreads();
+    lds_sync();
     const u64 out0 = s_out0;
     // first head after this wave's chunk
     uint32_t after = s_next;
@@ -806,6 +872,23 @@ struct PhaseTimer {
     }
     ~PhaseTimer() { finish(); }
 };
+
+#ifdef KK_STAMPS
+int read_stamps(unsigned long long *out16, bool reset) {
+    if (const char *e = getenv("KK_ABLATE")) {
+        int v = atoi(e);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ablate), &v, sizeof v);
+    }
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), 16 * sizeof(u64)) != hipSuccess) return -11;
+    if (reset) {
+        u64 z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z) != hipSuccess) return -11;
+    }
+    return 0;
+}
+#else
+int read_stamps(unsigned long long *, bool) { return -12; }
+#endif
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -256,6 +256,9 @@ int kmers_hip_profile_get(int i, char *name, size_t name_cap, double *ms_total, 
     return KMERS_OK;
 }
 
+// diagnostic builds only (-DKK_STAMPS): per-phase cycle sums of the scatter kernels; KMERS_ERR_BAD_ARG otherwise
+int kmers_hip_debug_stamps(unsigned long long *out16, int reset) { return kk::read_stamps(out16, reset != 0); }
+
 // ---- host merge of per-shard CSRs -------------------------------------------------------------------------
 
 int kmers_csr_merge(int n_parts, uint64_t n_rows, const float *const data[], const uint64_t *const row_ind[],

@@ -118,3 +118,13 @@ def test_row_pointer_gap_fill_paths(product, oracle, tmp_path):
     p.write_text(">a\nAAAAAAAAAAAAAC\n>b\nTTTTTTTTTTTTTT\n>c\nCATGCATGCATGCATGCA\n")
     for K in (11, 12, 14):
         kmtest.assert_x_equal(product.x([str(p)], K), oracle.x([str(p)], K))
+
+
+def test_one_giant_run(product, oracle, tmp_path):
+    """A single (k-mer, column) run that spans hundreds of tiles: the run-length reduce must find its end by search,
+    not by walking (a poly-A record is the worst case for the CSR emit)."""
+    p = tmp_path / "polya.fsa"
+    p.write_text(">a\n" + "A" * 3_000_000 + "\n>b\nACGTACGTACGT\n" + ">c\n" + "A" * 100_000 + "C\n")
+    for K in (8, 12):
+        kmtest.assert_x_equal(product.x([str(p)], K), oracle.x([str(p)], K))
+        assert np.array_equal(product.y([str(p)], K)[1], oracle.y([str(p)], K)[1])
