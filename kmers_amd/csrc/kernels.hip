@@ -293,22 +293,6 @@ __global__ __launch_bounds__(NT) void k_count_y_lds(BasesArgs a, int32_t *counts
 // X pass structure: per-tile digit histogram -> exclusive scan -> stable scatter
 // ------------------------------------------------------------------------------------------------------
 
-// Lanes of the wave that are ok and hold the same 8-bit digit as this lane (garbage for lanes that are not ok).
-// Per bit: t = 0 / ~0 from the lane's own bit (v_bfe_i32), one ballot (v_cmp), and "lanes that differ from me on this
-// bit" = ballot ^ t folded into the running mask with two 32-bit ops per half: 6 VALU per bit.
-__device__ __forceinline__ void match_digit(uint32_t d, u64 okm, uint32_t &m_lo, uint32_t &m_hi) {
-    uint32_t dl = 0, dh = 0;
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        const uint32_t t = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);
-        const u64 bal = __ballot(t != 0);
-        dl |= (uint32_t)bal ^ t;
-        dh |= (uint32_t)(bal >> 32) ^ t;
-    }
-    m_lo = ~dl & (uint32_t)okm;
-    m_hi = ~dh & (uint32_t)(okm >> 32);
-}
-
 // Pass 0 histogram, straight from the packed bases.  Also accumulates the number of valid windows per record
 // (the reference's total_count, src/libkmers.cpp:220-227) with one atomic per (wave round, record).
 __global__ __launch_bounds__(NT) void k_hist_bases(BasesArgs a, uint32_t *tilehist, uint32_t n_tiles, uint32_t *rec_total) {
@@ -396,8 +380,9 @@ __global__ __launch_bounds__(NT) void k_hist_entries(const u64 *ent, const uint3
 template <bool FROM_BASES>
 __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const u64 *in, const uint32_t *p_count, int shift,
                                                    const uint32_t *tilebase, uint32_t n_tiles, u64 *out) {
-    __shared__ u64 sent[TILE];
+    __shared__ u64 sent[TILE];          // entry staging; its first NW*RADIX words double as the match masks (below)
     __shared__ uint32_t wcnt[NW][RADIX];
+    static_assert(NW * RADIX <= TILE, "match masks alias the entry staging");
     __shared__ uint32_t gadj[RADIX];    // global base of (digit, tile) minus tstart[digit]
     __shared__ uint32_t stmp[NW];
     __shared__ TileLds L;               // only touched when FROM_BASES
@@ -428,7 +413,10 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const u64 *in, c
     KK_STAMP_BEGIN();
     for (uint32_t tile = t0; tile < t1; ++tile) {
         const uint64_t base = (uint64_t)tile * TILE;
-        for (uint32_t i = tid; i < NW * RADIX; i += NT) (&wcnt[0][0])[i] = 0;
+        for (uint32_t i = tid; i < NW * RADIX; i += NT) {
+            (&wcnt[0][0])[i] = 0;
+            sent[i] = 0ull;  // the match masks must start (and, by construction, end) a tile all zero
+        }
         if (FROM_BASES) {
             tile_commit<true>(L, pf, stmp);
             if (tile + 1 < t1) pf = tile_fetch<true>(a, tile + 1);
@@ -442,6 +430,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const u64 *in, c
         KK_STAMP(0);  // zero + commit/barrier
         const uint32_t n_valid = FROM_BASES ? (uint32_t)TILE : (uint32_t)((E - base < TILE) ? E - base : TILE);
         uint32_t *const wrow = &wcnt[w][0];
+        u64 *const wmask = &sent[w * RADIX];
         uint32_t rank[IPT];
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
@@ -457,16 +446,25 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const u64 *in, c
                 ok = wl + j * 64 < n_valid;
             }
             const uint32_t d = __builtin_amdgcn_ubfe(entry_key(e[j]), (uint32_t)shift, 8u);
-            uint32_t m_lo, m_hi;
-            if (KK_ABLATE(4)) {
-                m_lo = ok ? (1u << (lane & 31)) : 0u, m_hi = 0;
-            } else
-                match_digit(d, __ballot(ok), m_lo, m_hi);
+            // Match by LDS: every ok lane ORs its lane bit into the 64-bit word of (wave, digit); reading the word
+            // back gives the lanes of this round that share the digit.  The LDS executes a wave's instructions in
+            // order, so the read sees all 64 ORs; OR is order-independent, so the ranks are deterministic.  The lowest
+            // lane of each group advances the (wave, digit) counter and clears the word for the next round.
+            // (An 8-ballot match in registers gives the same masks for ~45 more VALU instructions per round.)
+            u64 m = 0;
             uint32_t before = 0;
-            if (ok) before = wrow[d];
+            if (ok) {
+                atomicOr(&wmask[d], 1ull << lane);
+                m = wmask[d];
+                before = wrow[d];
+            }
+            const uint32_t m_lo = (uint32_t)m, m_hi = (uint32_t)(m >> 32);
             const uint32_t below = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
             rank[j] = ok ? (before + below) : NONE;
-            if (ok && below == 0) wrow[d] = before + (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);  // lowest lane of the group
+            if (ok && below == 0) {
+                wrow[d] = before + (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);
+                wmask[d] = 0ull;
+            }
             asm volatile("" ::: "memory");  // the next round must re-read wcnt
             __builtin_amdgcn_sched_barrier(0);  // keep rounds apart: interleaving them only lengthens live ranges
         }
