@@ -30,7 +30,7 @@ extern "C" {
 #define KMERS_ERR_NO_DEVICE (-10)    /* no usable HIP device: this library has no CPU fallback     */
 #define KMERS_ERR_HIP (-11)          /* a HIP runtime call failed (message on stderr)              */
 #define KMERS_ERR_BAD_ARG (-12)      /* K outside 1..16, null pointer, bad mode/shard ...          */
-#define KMERS_ERR_TOO_LARGE (-13)    /* more than 2^32-2 sequence positions in one device call     */
+#define KMERS_ERR_TOO_LARGE (-13)    /* more than 2^32-65536 sequence positions in one device call     */
 #define KMERS_ERR_WORKSPACE (-14)    /* workspace smaller than kmers_hip_x_workspace_bytes()       */
 #define KMERS_ERR_NOMEM (-15)        /* host allocation failed                                     */
 

@@ -16,7 +16,7 @@ ERRORS = {
     -10: "libkmers: no usable HIP device (this library has no CPU fallback)",
     -11: "libkmers: HIP runtime error (see stderr)",
     -12: "libkmers: bad argument",
-    -13: "libkmers: input too large for one device call (more than 2^32-2 positions)",
+    -13: "libkmers: input too large for one device call (more than 2^32-65536 positions)",
     -14: "libkmers: workspace too small",
     -15: "libkmers: host allocation failed",
 }

@@ -85,6 +85,38 @@ __device__ __forceinline__ u64 make_entry(uint32_t key, uint32_t col) { return (
 __device__ __forceinline__ uint32_t entry_key(u64 e) { return (uint32_t)(e >> 32); }
 __device__ __forceinline__ uint32_t entry_col(u64 e) { return (uint32_t)e; }
 
+// ---- narrow entries (K <= 8 and at most 2^24 records): 4 bytes = one digit byte << 24 | column.
+// The partition is least-significant-digit first, so after a pass the digit that was just sorted on is implied by
+// the REGION an entry sits in (regions[d] = position of the first entry of digit d, regions[256] = entry count):
+//   pass 0 writes   (k-mer id >> 8) << 24 | column         into the regions of the low digit,
+//   pass 1 reads it, partitions on the top byte and writes   low digit << 24 | column   into the regions of the high digit,
+//   the run-length reduce rebuilds  k-mer id = region << 8 | top byte  (or = region when 2K <= 8 and there is one pass).
+// Half the bytes of the 8-byte form on every intermediate array; the 8-byte form serves K >= 9 or more records.
+__device__ __forceinline__ uint32_t region_search(const uint32_t *sreg, uint32_t i) {  // largest r with sreg[r] <= i
+    uint32_t lo = 0, hi = RADIX;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sreg[mid] <= i)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+// region of i given a lower bound `hint` (i < sreg[RADIX])
+__device__ __forceinline__ uint32_t region_from(const uint32_t *sreg, uint32_t i, uint32_t hint) {
+    uint32_t r = hint;
+    while (sreg[r + 1] <= i) ++r;
+    return r;
+}
+// regions[d] = tilebase[d][tile 0] of a scanned digit-major tile histogram; regions[256] = entry count
+__global__ void k_regions(const uint32_t *tilebase, uint32_t n_tiles, const uint32_t *p_count, uint32_t *regions) {
+    const uint32_t d = threadIdx.x;
+    if (d < RADIX) regions[d] = tilebase[(uint64_t)d * n_tiles];
+    if (d == RADIX) regions[RADIX] = *p_count;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release/acquire fence around
 // s_barrier, and on gfx950 global loads, stores and LDS ops are released by s_waitcnt vmcnt(0) / lgkmcnt(0): it would
 // drain every global prefetch and every write-out store at each barrier.  No kernel here passes GLOBAL data between
@@ -342,8 +374,10 @@ __global__ __launch_bounds__(NT) void k_hist_bases(BasesArgs a, uint32_t *tilehi
 }
 
 // Later-pass histogram over stored entries.  One tile per workgroup; tiles past the entry count write zeros.
-__global__ __launch_bounds__(NT) void k_hist_entries(const u64 *ent, const uint32_t *p_count, int shift, uint32_t *tilehist,
+template <class ET>
+__global__ __launch_bounds__(NT) void k_hist_entries(const ET *ent, const uint32_t *p_count, int shift, uint32_t *tilehist,
                                                      uint32_t n_tiles) {
+    constexpr bool NARROW = sizeof(ET) == 4;
     __shared__ uint32_t h[NW][RADIX];
     const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
     const uint32_t tile = blockIdx.x;
@@ -352,16 +386,21 @@ __global__ __launch_bounds__(NT) void k_hist_entries(const u64 *ent, const uint3
     for (uint32_t i = tid; i < NW * RADIX; i += NT) (&h[0][0])[i] = 0;
     lds_sync();
     if (base < E) {
-        u64 e[IPT];
+        ET e[IPT];
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             const uint64_t i = base + w * WCHUNK + j * 64 + lane;
-            e[j] = (i < E) ? ent[i] : ~0ull;
+            e[j] = (i < E) ? ent[i] : (ET)0;
         }
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             const uint64_t i = base + w * WCHUNK + j * 64 + lane;
-            if (i < E) atomicAdd(&h[w][(entry_key(e[j]) >> shift) & 255u], 1u);
+            uint32_t d;
+            if constexpr (NARROW)
+                d = (uint32_t)e[j] >> 24;
+            else
+                d = (entry_key((u64)e[j]) >> shift) & 255u;
+            if (i < E) atomicAdd(&h[w][d], 1u);
         }
     }
     lds_sync();
@@ -377,13 +416,17 @@ __global__ __launch_bounds__(NT) void k_hist_entries(const u64 *ent, const uint3
 // range [b*per, (b+1)*per) and fetches the next tile while the current one is ranked and written.
 //   FROM_BASES: entries are generated from the packed store (pass 0); otherwise read from `in`.
 //   tilebase = exclusive scan of the digit-major tile histogram: global position of the first entry of (digit, tile).
-template <bool FROM_BASES>
-__global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const u64 *in, const uint32_t *p_count, int shift,
-                                                   const uint32_t *tilebase, uint32_t n_tiles, u64 *out) {
-    __shared__ u64 sent[TILE];          // entry staging; its first NW*RADIX words double as the match masks (below)
+template <bool FROM_BASES, class ET>
+__global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, const uint32_t *p_count, int shift,
+                                                   const uint32_t *tilebase, uint32_t n_tiles, ET *out, const uint32_t *regions) {
+    constexpr bool NARROW = sizeof(ET) == 4;
+    // entry staging; its first NW*RADIX 8-byte words double as the match masks (below)
+    __shared__ __attribute__((aligned(16))) ET sent[TILE];
+    __shared__ uint8_t saux[NARROW ? TILE : 4];  // narrow: pass 0 the partition digit, pass 1 the byte that replaces it
+    __shared__ uint32_t sreg[NARROW ? RADIX + 1 : 1];
     __shared__ uint32_t wcnt[NW][RADIX];
-    static_assert(NW * RADIX <= TILE, "match masks alias the entry staging");
-    __shared__ uint32_t gadj[RADIX];    // global base of (digit, tile) minus tstart[digit]
+    static_assert(NW * RADIX * 8 <= TILE * 4, "match masks alias the entry staging");
+    __shared__ uint32_t gadj[RADIX];    // global base of (digit, tile) minus the digit's first tile-local slot
     __shared__ uint32_t stmp[NW];
     __shared__ TileLds L;               // only touched when FROM_BASES
 
@@ -396,16 +439,29 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const u64 *in, c
     const uint32_t per = (nt + gridDim.x - 1) / gridDim.x;
     const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < nt) ? t0 + per : nt;
     if (t0 >= t1) return;
+    u64 *const smask = reinterpret_cast<u64 *>(sent);
 
-    u64 e[IPT];
+    ET e[IPT];
+    uint32_t aux[IPT];   // narrow pass 1: the region (= previous digit) of each entry, found when the load is issued
+    uint32_t rhint = 0;
     TilePf pf;
     if (FROM_BASES) {
         pf = tile_fetch<true>(a, t0);
     } else {
+        if constexpr (NARROW) {
+            for (uint32_t i = tid; i <= RADIX; i += NT) sreg[i] = regions[i];
+            lds_sync();
+            const uint32_t i0 = t0 * TILE + w * WCHUNK;
+            rhint = region_search(sreg, i0 < E ? i0 : (E ? E - 1 : 0));
+        }
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             const uint64_t i = (uint64_t)t0 * TILE + w * WCHUNK + j * 64 + lane;
-            e[j] = (i < E) ? in[i] : 0ull;
+            e[j] = (i < E) ? in[i] : (ET)0;
+            if constexpr (NARROW) {
+                if (i < E) rhint = region_from(sreg, (uint32_t)i, rhint);
+                aux[j] = rhint;
+            }
         }
     }
     uint32_t gb = (tid < RADIX) ? tilebase[(uint64_t)tid * n_tiles + t0] : 0u;
@@ -415,7 +471,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const u64 *in, c
         const uint64_t base = (uint64_t)tile * TILE;
         for (uint32_t i = tid; i < NW * RADIX; i += NT) {
             (&wcnt[0][0])[i] = 0;
-            sent[i] = 0ull;  // the match masks must start (and, by construction, end) a tile all zero
+            smask[i] = 0ull;  // the match masks must start (and, by construction, end) a tile all zero
         }
         if (FROM_BASES) {
             tile_commit<true>(L, pf, stmp);
@@ -430,22 +486,35 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const u64 *in, c
         KK_STAMP(0);  // zero + commit/barrier
         const uint32_t n_valid = FROM_BASES ? (uint32_t)TILE : (uint32_t)((E - base < TILE) ? E - base : TILE);
         uint32_t *const wrow = &wcnt[w][0];
-        u64 *const wmask = &sent[w * RADIX];
-        uint32_t rank[IPT];
+        u64 *const wmask = &smask[w * RADIX];
+        uint32_t rank[IPT];  // bits 0..15 rank inside (wave, digit); narrow: bits 16..23 the aux byte; NONE = no entry
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             bool ok;
+            uint32_t d, ab = 0;
             if (FROM_BASES) {
                 const uint32_t o = wl + j * 64;
                 uint32_t key;
                 ok = window_at(L, o, a.K, key);
                 uint32_t col = record_at(L, o);
                 asm volatile("" : "+v"(col));  // finish the column now: sunk to its use it keeps 4 LDS words per round alive
-                e[j] = make_entry(key, col);
+                if constexpr (NARROW) {
+                    d = key & 255u;
+                    ab = d;
+                    e[j] = ((key >> 8) << 24) | col;
+                } else {
+                    d = __builtin_amdgcn_ubfe(key, (uint32_t)shift, 8u);
+                    e[j] = make_entry(key, col);
+                }
             } else {
                 ok = wl + j * 64 < n_valid;
+                if constexpr (NARROW) {
+                    d = (uint32_t)e[j] >> 24;
+                    ab = aux[j];
+                } else {
+                    d = __builtin_amdgcn_ubfe(entry_key((u64)e[j]), (uint32_t)shift, 8u);
+                }
             }
-            const uint32_t d = __builtin_amdgcn_ubfe(entry_key(e[j]), (uint32_t)shift, 8u);
             // Match by LDS: every ok lane ORs its lane bit into the 64-bit word of (wave, digit); reading the word
             // back gives the lanes of this round that share the digit.  The LDS executes a wave's instructions in
             // order, so the read sees all 64 ORs; OR is order-independent, so the ranks are deterministic.  The lowest
@@ -460,7 +529,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const u64 *in, c
             }
             const uint32_t m_lo = (uint32_t)m, m_hi = (uint32_t)(m >> 32);
             const uint32_t below = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
-            rank[j] = ok ? (before + below) : NONE;
+            rank[j] = ok ? ((before + below) | (ab << 16)) : NONE;
             if (ok && below == 0) {
                 wrow[d] = before + (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);
                 wmask[d] = 0ull;
@@ -495,8 +564,14 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const u64 *in, c
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             if (rank[j] != NONE) {
-                const uint32_t d = __builtin_amdgcn_ubfe(entry_key(e[j]), (uint32_t)shift, 8u);
-                sent[wrow[d] + rank[j]] = e[j];
+                uint32_t d;
+                if constexpr (NARROW)
+                    d = FROM_BASES ? ((rank[j] >> 16) & 255u) : ((uint32_t)e[j] >> 24);
+                else
+                    d = __builtin_amdgcn_ubfe(entry_key((u64)e[j]), (uint32_t)shift, 8u);
+                const uint32_t slot = wrow[d] + (rank[j] & 0xFFFFu);
+                sent[slot] = e[j];
+                if constexpr (NARROW) saux[slot] = (uint8_t)(rank[j] >> 16);
             }
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
@@ -504,16 +579,31 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const u64 *in, c
 #pragma unroll
             for (int j = 0; j < IPT; ++j) {
                 const uint64_t i = base + TILE + w * WCHUNK + j * 64 + lane;
-                e[j] = (i < E) ? in[i] : 0ull;
+                e[j] = (i < E) ? in[i] : (ET)0;
+                if constexpr (NARROW) {
+                    if (i < E) rhint = region_from(sreg, (uint32_t)i, rhint);
+                    aux[j] = rhint;
+                }
             }
         }
         KK_STAMP(4);  // LDS scatter + prefetch issue
         lds_sync();
         KK_STAMP(5);  // barrier
         for (uint32_t i = tid; i < tile_count; i += NT) {
-            const u64 v = sent[i];
-            const uint32_t dst = gadj[__builtin_amdgcn_ubfe(entry_key(v), (uint32_t)shift, 8u)] + i;
-            if (!KK_ABLATE(1) || v == 0x123456789abcdefull) out[dst] = v;
+            ET v = sent[i];
+            uint32_t d;
+            if constexpr (NARROW) {
+                const uint32_t ab = saux[i];
+                if (FROM_BASES) {
+                    d = ab;
+                } else {
+                    d = (uint32_t)v >> 24;
+                    v = ((uint32_t)v & 0xFFFFFFu) | (ab << 24);  // the digit sorted on is implied by the region from now on
+                }
+            } else {
+                d = __builtin_amdgcn_ubfe(entry_key((u64)v), (uint32_t)shift, 8u);
+            }
+            if (!KK_ABLATE(1)) out[gadj[d] + i] = v;
         }
         KK_STAMP(6);  // write-out
         lds_sync();
@@ -655,9 +745,15 @@ __device__ __forceinline__ u64 lookback_exclusive(u64 *status, uint32_t tile, u6
 // One CSR entry per head (first instance of a (k-mer, column) run): column, value, and the row pointer entries of
 // every row that starts (or is empty) between the previous head's k-mer and this one.
 //   scal[0] = E (instances, input), scal[1] = nnz (output), scal[2] = ntasks, scal[3] = err, scal[5] = ticket
-__global__ __launch_bounds__(NT, 4) void k_rle(const u64 *ent, uint32_t *scal, u64 *status, const uint32_t *rec_total,
+// Narrow entries are widened to the 8-byte form (k-mer id << 32 | column) as they are loaded (the id's upper part is
+// the region the entry sits in), so everything after the loads is common to both forms.
+template <class ET>
+__global__ __launch_bounds__(NT, 4) void k_rle(const ET *ent, uint32_t *scal, u64 *status, const uint32_t *rec_total,
                                                uint64_t first_col, uint64_t M, uint64_t max_nz, float *data, uint64_t *col_ind,
-                                               uint64_t *row_ind, FillTask *tasks, uint32_t task_cap) {
+                                               uint64_t *row_ind, FillTask *tasks, uint32_t task_cap, const uint32_t *regions,
+                                               int key_shift) {
+    constexpr bool NARROW = sizeof(ET) == 4;
+    __shared__ uint32_t sreg[NARROW ? RADIX + 1 : 1];
     __shared__ uint32_t s_tile;
     __shared__ uint32_t s_cnt[NW], s_first[NW];
     __shared__ uint32_t s_next;   // first head after this tile (index), E if none
@@ -666,8 +762,21 @@ __global__ __launch_bounds__(NT, 4) void k_rle(const u64 *ent, uint32_t *scal, u
     uint32_t *p_nnz = &scal[1], *p_ntasks = &scal[2], *p_err = &scal[3];
     const uint32_t E = scal[0];
     if (tid == 0) s_tile = atomicAdd(&scal[5], 1u);
+    if constexpr (NARROW)
+        for (uint32_t i = tid; i <= RADIX; i += NT) sreg[i] = regions[i];
     lds_sync();
     const uint32_t tile = s_tile;
+    // entry i in the 8-byte form; `r` = its region if already known, NONE to search for it
+    auto wide_at = [&](uint64_t i, uint32_t r) -> u64 {
+        if constexpr (NARROW) {
+            const uint32_t v = ent[i];
+            if (r == NONE) r = region_search(sreg, (uint32_t)i);
+            const uint32_t key = key_shift ? ((r << 8) | (v >> 24)) : r;
+            return make_entry(key, v & 0xFFFFFFu);
+        } else {
+            return ent[i];
+        }
+    };
     if (E == 0) {  // no instance at all: every row pointer is 0
         if (tile == 0 && tid == 0) fill_rows(row_ind, 0, M + 1, 0, tasks, p_ntasks, task_cap, p_err);
         return;
@@ -678,12 +787,35 @@ __global__ __launch_bounds__(NT, 4) void k_rle(const u64 *ent, uint32_t *scal, u
 
     // ---- load, head flags
     u64 e[IPT];
+    if constexpr (NARROW) {
+        uint32_t v[IPT];  // all loads in flight before any region work
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-        const uint64_t i = (uint64_t)wbase_i + j * 64 + lane;
-        e[j] = (i < E) ? ent[i] : ~0ull;
+        for (int j = 0; j < IPT; ++j) {
+            const uint64_t i = (uint64_t)wbase_i + j * 64 + lane;
+            v[j] = (i < E) ? ent[i] : 0u;
+        }
+        const uint32_t r0 = region_search(sreg, wbase_i < E ? wbase_i : E - 1);  // wave-uniform lower bound
+        const bool one_region = sreg[r0 + 1] >= wbase_i + WCHUNK || sreg[r0 + 1] >= E;  // nearly always: 256 regions
+        uint32_t r = r0;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t i = wbase_i + j * 64 + lane;
+            if (i < E) {
+                if (!one_region) r = region_from(sreg, i, r);
+                const uint32_t key = key_shift ? ((r << 8) | (v[j] >> 24)) : r;
+                e[j] = make_entry(key, v[j] & 0xFFFFFFu);
+            } else {
+                e[j] = ~0ull;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint64_t i = (uint64_t)wbase_i + j * 64 + lane;
+            e[j] = (i < E) ? ent[i] : ~0ull;
+        }
     }
-    const u64 carry0 = (wbase_i > 0 && lane == 0) ? ent[wbase_i - 1] : 0ull;  // the entry before this wave's chunk
+    const u64 carry0 = (wbase_i > 0 && lane == 0) ? wide_at(wbase_i - 1, NONE) : 0ull;  // the entry before this wave's chunk
     u64 carry = carry0;
     u64 hm[IPT], rm[IPT];  // head lanes / heads that also start a new row (wave-uniform masks)
     uint32_t cnt = 0;
@@ -716,9 +848,9 @@ __global__ __launch_bounds__(NT, 4) void k_rle(const u64 *ent, uint32_t *scal, u
         const uint64_t tile_end = base + TILE;
         uint32_t nxt = E;
         if (tile_end < E) {
-            const u64 last = ent[tile_end - 1];
+            const u64 last = wide_at(tile_end - 1, NONE);
             const uint64_t i = tile_end + lane;
-            const u64 dm = __ballot((i < E) ? (ent[i] != last) : true);
+            const u64 dm = __ballot((i < E) ? (wide_at(i, NONE) != last) : true);
             if (dm) {
                 const uint64_t at = tile_end + (uint32_t)__ffsll((long long)dm) - 1u;
                 nxt = (at < E) ? (uint32_t)at : E;
@@ -726,7 +858,7 @@ __global__ __launch_bounds__(NT, 4) void k_rle(const u64 *ent, uint32_t *scal, u
                 uint64_t lo = tile_end + 64, hi = E;  // first index in [lo, hi] whose entry is > last
                 while (lo < hi) {
                     const uint64_t mid = (lo + hi) >> 1;
-                    if (ent[mid] > last)
+                    if (wide_at(mid, NONE) > last)
                         hi = mid;
                     else
                         lo = mid + 1;
@@ -895,8 +1027,8 @@ struct XLayout {
     uint64_t hist_len;       // RADIX * n_tiles
     uint32_t scan_blocks;
     uint32_t task_cap;
-    size_t off_entA, off_entB, off_hist, off_blocksums, off_total, off_flags, off_tilecb, off_status, off_scalars, off_tasks,
-        bytes;
+    size_t off_entA, off_entB, off_hist, off_blocksums, off_total, off_flags, off_tilecb, off_status, off_scalars, off_regions,
+        off_tasks, bytes;
 };
 
 static XLayout x_layout(uint64_t n_pos, uint64_t n_rec, int K) {
@@ -926,6 +1058,7 @@ static XLayout x_layout(uint64_t n_pos, uint64_t n_rec, int K) {
     l.off_tilecb = take(((size_t)l.n_tiles + 2) * 4);
     l.off_status = take(((size_t)l.n_tiles + 1) * 8);
     l.off_scalars = take(64);
+    l.off_regions = take(2 * (RADIX + 1) * 4);
     l.off_tasks = take((size_t)l.task_cap * sizeof(FillTask));
     l.bytes = o;
     return l;
@@ -1007,30 +1140,58 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     const dim3 hgrid(l.n_tiles < 2048u ? l.n_tiles : 2048u);
     const int n_pass = (2 * K + 7) / 8;
 
-    // pass 0: packed bases -> (key, col) instances partitioned by the lowest digit
+    // K <= 8 and at most 2^24 records: 4-byte entries (digit byte << 24 | column), else 8-byte (k-mer id << 32 | column)
+    const bool narrow = (K <= 8) && (n_rec <= (1ull << 24)) && !getenv("KMERS_FORCE_WIDE");  // env: tests / A-B runs
+    uint32_t *regs0 = (uint32_t *)(ws + l.off_regions), *regs1 = regs0 + (RADIX + 1);
+    const uint32_t *c_hist = hist, *c_E = &scal[0];
+
+    // pass 0: packed bases -> instances partitioned by the lowest digit
     hipLaunchKernelGGL(k_hist_bases, hgrid, block, 0, s, a, hist, l.n_tiles, total);
     pt.mark("k_hist_bases");
     if (int rc = scan_u32(hist, l.hist_len, hist, bsum, l.scan_blocks, &scal[0], s)) return rc;
     pt.mark("k_scan");
-    hipLaunchKernelGGL(k_scatter<true>, pgrid, block, 0, s, a, (const u64 *)nullptr, (const uint32_t *)&scal[0], 0,
-                       (const uint32_t *)hist, l.n_tiles, entA);
-    pt.mark("k_scatter<bases>");
-    u64 *ei = entA, *eo = entB;
-    for (int p = 1; p < n_pass; ++p) {
-        const int shift = 8 * p;
-        hipLaunchKernelGGL(k_hist_entries, grid, block, 0, s, (const u64 *)ei, (const uint32_t *)&scal[0], shift, hist, l.n_tiles);
-        pt.mark("k_hist_entries");
-        if (int rc = scan_u32(hist, l.hist_len, hist, bsum, l.scan_blocks, &scal[4], s)) return rc;
-        pt.mark("k_scan");
-        hipLaunchKernelGGL(k_scatter<false>, pgrid, block, 0, s, a, (const u64 *)ei, (const uint32_t *)&scal[0], shift,
-                           (const uint32_t *)hist, l.n_tiles, eo);
-        pt.mark("k_scatter<entries>");
-        u64 *t = ei;
-        ei = eo, eo = t;
+    const uint32_t *final_regions = regs0;
+    if (narrow) {
+        uint32_t *ei = (uint32_t *)entA, *eo = (uint32_t *)entB;
+        hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, l.n_tiles, c_E, regs0);
+        hipLaunchKernelGGL((k_scatter<true, uint32_t>), pgrid, block, 0, s, a, (const uint32_t *)nullptr, c_E, 0, c_hist, l.n_tiles,
+                           ei, (const uint32_t *)nullptr);
+        pt.mark("k_scatter<bases>");
+        if (n_pass > 1) {
+            hipLaunchKernelGGL(k_hist_entries<uint32_t>, grid, block, 0, s, (const uint32_t *)ei, c_E, 8, hist, l.n_tiles);
+            pt.mark("k_hist_entries");
+            if (int rc = scan_u32(hist, l.hist_len, hist, bsum, l.scan_blocks, &scal[4], s)) return rc;
+            pt.mark("k_scan");
+            hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, l.n_tiles, c_E, regs1);
+            hipLaunchKernelGGL((k_scatter<false, uint32_t>), pgrid, block, 0, s, a, (const uint32_t *)ei, c_E, 8, c_hist, l.n_tiles, eo,
+                               (const uint32_t *)regs0);
+            pt.mark("k_scatter<entries>");
+            uint32_t *t = ei;
+            ei = eo, eo = t;
+            final_regions = regs1;
+        }
+        hipLaunchKernelGGL(k_rle<uint32_t>, grid, block, 0, s, (const uint32_t *)ei, scal, status, (const uint32_t *)total, first_col, M,
+                           max_nz, d_data, d_col_ind, d_row_ind, tasks, l.task_cap, final_regions, n_pass > 1 ? 8 : 0);
+    } else {
+        u64 *ei = entA, *eo = entB;
+        hipLaunchKernelGGL((k_scatter<true, u64>), pgrid, block, 0, s, a, (const u64 *)nullptr, c_E, 0, c_hist, l.n_tiles, ei,
+                           (const uint32_t *)nullptr);
+        pt.mark("k_scatter<bases>");
+        for (int p = 1; p < n_pass; ++p) {
+            const int shift = 8 * p;
+            hipLaunchKernelGGL(k_hist_entries<u64>, grid, block, 0, s, (const u64 *)ei, c_E, shift, hist, l.n_tiles);
+            pt.mark("k_hist_entries");
+            if (int rc = scan_u32(hist, l.hist_len, hist, bsum, l.scan_blocks, &scal[4], s)) return rc;
+            pt.mark("k_scan");
+            hipLaunchKernelGGL((k_scatter<false, u64>), pgrid, block, 0, s, a, (const u64 *)ei, c_E, shift, c_hist, l.n_tiles, eo,
+                               (const uint32_t *)nullptr);
+            pt.mark("k_scatter<entries>");
+            u64 *t = ei;
+            ei = eo, eo = t;
+        }
+        hipLaunchKernelGGL(k_rle<u64>, grid, block, 0, s, (const u64 *)ei, scal, status, (const uint32_t *)total, first_col, M, max_nz,
+                           d_data, d_col_ind, d_row_ind, tasks, l.task_cap, (const uint32_t *)nullptr, 0);
     }
-    // run-length reduce -> CSR
-    hipLaunchKernelGGL(k_rle, grid, block, 0, s, (const u64 *)ei, scal, status, (const uint32_t *)total, first_col, M, max_nz,
-                       d_data, d_col_ind, d_row_ind, tasks, l.task_cap);
     pt.mark("k_rle");
     hipLaunchKernelGGL(k_fill_tasks, dim3(2048), block, 0, s, d_row_ind, (const FillTask *)tasks, (const uint32_t *)&scal[2],
                        l.task_cap);

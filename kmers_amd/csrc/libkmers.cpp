@@ -131,7 +131,7 @@ int build_files(int n_files, const char *fnames[], int K, int L, int mode, float
     if (int rc = select_device()) return rc;
     const kmers_store *st = g.s;
     const uint64_t n_pos = kmers_store_n_pos(st), n_rec = kmers_store_n_rec(st);
-    if (n_pos > 0xFFFFFFFEull || n_rec > 0x7FFFFFFFull) return KMERS_ERR_TOO_LARGE;
+    if (n_pos > 0xFFFF0000ull || n_rec > 0x7FFFFFFFull) return KMERS_ERR_TOO_LARGE;
     const uint64_t M = 1ull << (2 * K);
     const uint64_t windows = kmers_store_n_windows(st, K);   // upper bound on nnz
     const uint64_t cap = std::min<uint64_t>(max_size, windows);
@@ -233,7 +233,7 @@ int kmers_hip_build_x(const uint32_t *d_bases, size_t bases_words, const uint32_
     if (n_pos && (!d_bases || !d_valid || !d_rec_start)) return KMERS_ERR_BAD_ARG;
     if (max_nz && (!d_data || !d_col_ind)) return KMERS_ERR_BAD_ARG;
     if (bases_words < (n_pos + 15) / 16 || valid_words < (n_pos + 31) / 32) return KMERS_ERR_BAD_ARG;
-    if (n_pos > 0xFFFFFFFEull || n_rec > 0x7FFFFFFFull) return KMERS_ERR_TOO_LARGE;
+    if (n_pos > 0xFFFF0000ull || n_rec > 0x7FFFFFFFull) return KMERS_ERR_TOO_LARGE;
     return kk::build_x(d_bases, bases_words, d_valid, valid_words, d_rec_start, n_pos, n_rec, first_col, K, d_data, d_col_ind,
                        d_row_ind, max_nz, d_workspace, workspace_bytes, nnz_out, (hipStream_t)stream);
 }

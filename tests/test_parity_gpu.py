@@ -50,6 +50,14 @@ def test_x_random_vs_oracle(product, oracle, syn, K):
     kmtest.assert_x_equal(a, b)
 
 
+@pytest.mark.parametrize("K", [2, 4, 5, 8])
+def test_x_wide_entries_for_small_k(product, oracle, syn, K, monkeypatch):
+    """K <= 8 normally runs on 4-byte entries; KMERS_FORCE_WIDE selects the 8-byte form (used for K >= 9 or more
+    than 2^24 records), which must give the same matrix."""
+    monkeypatch.setenv("KMERS_FORCE_WIDE", "1")
+    kmtest.assert_x_equal(product.x([syn["iso"], syn["uni"]], K), oracle.x([syn["iso"], syn["uni"]], K))
+
+
 @pytest.mark.parametrize("K,L,cat", [(8, 1500, False), (12, 0, True), (6, 2000, True), (14, 0, False)])
 def test_x_variants_vs_oracle(product, oracle, syn, K, L, cat):
     files = [syn["iso"], syn["uni"]]
