@@ -155,10 +155,11 @@ def main():
             nnz = ds.build_x(buf)
     else:
         counts = torch.zeros(M, dtype=torch.int32, device=dev)
+        y_ws = ds.y_workspace(K)             # K >= 9: partition scratch, kept across steps
 
         def step():
             counts.zero_()
-            ds.count_y(K, counts)
+            ds.count_y(K, counts, workspace=y_ws)
             if world > 1:
                 dist.all_reduce(counts)      # RCCL ring over xGMI: the reference's shared-array "+=" across GPUs
 
@@ -192,29 +193,37 @@ def main():
         value = windows_all * args.steps / dt_max
         # ---- algorithmic bytes per rank
         B = n_bases
+        E = instances
         if kind_x:
             path_bytes = B / 4 + B / 8 + 8 * (n_rec + 1) + nnz * 12 + 8 * (M + 1)
-            E = instances
+            es = 4 if (K <= 8 and n_rec <= 1 << 24) else 8      # bytes per partition entry
             # what each kernel has to move at minimum for its own job (per launch)
             kernel_bytes = {
                 "k_hist_bases": n_pos * 3 / 8 + 8 * (n_rec + 1),
-                "k_scatter<bases>": n_pos * 3 / 8 + 8 * (n_rec + 1) + 8 * E,
-                "k_hist_keys": 4 * E,
-                "k_scatter<keys>": 16 * E,
-                "k_rle_count": 8 * E,
-                "k_rle_emit": 8 * E + 12 * nnz + 8 * (M + 1),
+                "k_scatter<bases>": n_pos * 3 / 8 + 8 * (n_rec + 1) + es * E,
+                "k_hist_entries": es * E,
+                "k_scatter<entries>": 2 * es * E,
+                "k_rle": es * E + 12 * nnz + 8 * (M + 1),
             }
-            dom = max((r for r in table if r[0] in kernel_bytes), key=lambda r: r[1], default=None)
         else:
             path_bytes = B / 4 + B / 8 + 4 * M
-            kernel_bytes, dom = {}, None
+            kernel_bytes = {
+                "k_count_y_lds": n_pos * 3 / 8 * (2 if K == 8 else 1) + 4 * M,
+                "k_count_y_global": n_pos * 3 / 8 + 8 * E,
+                "k_hist_bases<y>": n_pos * 3 / 8,
+                "k_scatter<bases,y>": n_pos * 3 / 8 + 4 * E,
+                "k_hist_entries": 4 * E,
+                "k_scatter<entries>": 8 * E,
+                "k_count_y_sorted": 4 * E + 8 * M,
+            }
+        dom = max((r for r in table if r[0] in kernel_bytes), key=lambda r: r[1], default=None)
         roof = None
         if dom is not None:
             avg_ms = dom[1] / dom[2]
             ach = kernel_bytes[dom[0]] / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(avg_ms, 4),
-                    "algorithmic_bytes": int(kernel_bytes[dom[0]])}
+                    "launches_per_step": dom[2] // max(args.steps, 1), "algorithmic_bytes": int(kernel_bytes[dom[0]])}
         else:
             ach = path_bytes / (ms_per_step * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "k_count_y", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

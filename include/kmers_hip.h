@@ -82,9 +82,23 @@ int kmers_hip_device_count(void);
 
 /* y: for every position p with valid[p .. p+K) all set, counts[id(p)] += 1.
  * d_counts is int32[4^K] in HBM and is ADDED to (the caller zeroes it), like the reference's histogram.
- * Asynchronous on `stream`. */
+ * K <= 8: LDS-privatised histograms, asynchronous on `stream`.  K >= 9: the k-mers are partitioned by their top
+ * 8 or 16 bits in a scratch buffer and counted slice by slice; this call allocates that buffer itself and therefore
+ * synchronises `stream` before returning -- use kmers_hip_count_y_ws to bring the buffer and stay asynchronous.
+ * Calls that add into the same d_counts must not overlap (K >= 9 adds with plain read-modify-writes). */
 int kmers_hip_count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words,
                       uint64_t n_pos, int K, int32_t *d_counts, void *stream);
+
+/* Recommended scratch bytes for kmers_hip_count_y_ws (0 for K <= 8): 4 bytes per position (8 for K >= 13) plus
+ * the tile histogram, for chunks of at most 2^31 positions. */
+size_t kmers_hip_y_workspace_bytes(uint64_t n_pos, int K);
+
+/* kmers_hip_count_y with a caller-owned scratch buffer; asynchronous on `stream`, no allocation.  Any size down to
+ * one 8192-position tile's worth is accepted (KMERS_ERR_WORKSPACE below that): a smaller buffer means more,
+ * smaller chunks.  No counterpart in the reference. */
+int kmers_hip_count_y_ws(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words,
+                         uint64_t n_pos, int K, int32_t *d_counts, void *d_workspace, size_t workspace_bytes,
+                         void *stream);
 
 /* Bytes of scratch HBM kmers_hip_build_x needs for a store of n_pos positions / n_rec records. */
 size_t kmers_hip_x_workspace_bytes(uint64_t n_pos, uint64_t n_rec, int K);

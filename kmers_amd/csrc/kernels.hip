@@ -158,6 +158,8 @@ struct BasesArgs {
     uint64_t bases_words, valid_words;
     uint64_t n_pos;
     int K;
+    uint64_t tile0;  // y in chunks: the kernel's tile t is tile tile0 + t of the store (X: 0)
+    int low_bits;    // y for K >= 9: the k-mer id is split into a sort key (id >> low_bits) and a payload (the low bits)
 };
 
 struct TileLds {
@@ -173,9 +175,10 @@ struct TilePf {  // one tile's words, held in registers between fetch and commit
 };
 
 template <bool WITH_REC>
-__device__ __forceinline__ TilePf tile_fetch(const BasesArgs &a, uint64_t tile) {
+__device__ __forceinline__ TilePf tile_fetch(const BasesArgs &a, uint64_t local_tile) {
     const uint32_t tid = threadIdx.x;
     TilePf p;
+    const uint64_t tile = local_tile + a.tile0;
     const uint64_t bw = tile * (TILE / 16) + tid;
     p.b0 = (bw < a.bases_words) ? a.bases[bw] : 0u;
     p.b1 = 0u;
@@ -189,7 +192,7 @@ __device__ __forceinline__ TilePf tile_fetch(const BasesArgs &a, uint64_t tile) 
     p.cb = 0u;
     if (WITH_REC) {
         p.f = (tid < TILE / 32 && vw < a.valid_words) ? a.rec_flags[vw] : 0u;
-        p.cb = a.tile_cb[tile];
+        p.cb = a.tile_cb[local_tile];
     }
     return p;
 }
@@ -327,6 +330,8 @@ __global__ __launch_bounds__(NT) void k_count_y_lds(BasesArgs a, int32_t *counts
 
 // Pass 0 histogram, straight from the packed bases.  Also accumulates the number of valid windows per record
 // (the reference's total_count, src/libkmers.cpp:220-227) with one atomic per (wave round, record).
+// YKEYS (y for K >= 9): the digit is taken from the sort key id >> low_bits and there are no records.
+template <bool YKEYS>
 __global__ __launch_bounds__(NT) void k_hist_bases(BasesArgs a, uint32_t *tilehist, uint32_t n_tiles, uint32_t *rec_total) {
     __shared__ TileLds L;
     __shared__ uint32_t stmp[NW];
@@ -335,19 +340,20 @@ __global__ __launch_bounds__(NT) void k_hist_bases(BasesArgs a, uint32_t *tilehi
     const uint32_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
     const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
     if (t0 >= t1) return;
-    TilePf pf = tile_fetch<true>(a, t0);
+    TilePf pf = tile_fetch<!YKEYS>(a, t0);
     for (uint32_t tile = t0; tile < t1; ++tile) {
         for (uint32_t i = tid; i < NW * RADIX; i += NT) (&h[0][0])[i] = 0;
-        tile_commit<true>(L, pf, stmp);
-        if (tile + 1 < t1) pf = tile_fetch<true>(a, tile + 1);
+        tile_commit<!YKEYS>(L, pf, stmp);
+        if (tile + 1 < t1) pf = tile_fetch<!YKEYS>(a, tile + 1);
 #pragma unroll 2
         for (int j = 0; j < IPT; ++j) {
             const uint32_t o = w * WCHUNK + j * 64 + lane;
             uint32_t key;
             const bool ok = window_at(L, o, a.K, key);
+            if (YKEYS) key >>= a.low_bits;
             if (ok) atomicAdd(&h[w][key & 255u], 1u);
             // valid windows per record: lanes are position-ordered, so records form contiguous lane segments
-            const u64 okm = __ballot(ok);
+            const u64 okm = YKEYS ? 0ull : __ballot(ok);
             if (okm) {
                 const uint32_t rec = record_at(L, o);
                 const uint32_t prev = __shfl_up(rec, 1);
@@ -416,10 +422,12 @@ __global__ __launch_bounds__(NT) void k_hist_entries(const ET *ent, const uint32
 // range [b*per, (b+1)*per) and fetches the next tile while the current one is ranked and written.
 //   FROM_BASES: entries are generated from the packed store (pass 0); otherwise read from `in`.
 //   tilebase = exclusive scan of the digit-major tile histogram: global position of the first entry of (digit, tile).
-template <bool FROM_BASES, class ET>
+//   YKEYS (y for K >= 9, narrow entries from the bases): sort key = id >> low_bits, payload = the low bits, no records.
+template <bool FROM_BASES, class ET, bool YKEYS = false>
 __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, const uint32_t *p_count, int shift,
                                                    const uint32_t *tilebase, uint32_t n_tiles, ET *out, const uint32_t *regions) {
     constexpr bool NARROW = sizeof(ET) == 4;
+    static_assert(!YKEYS || (FROM_BASES && NARROW), "y keys are generated from the bases as narrow entries");
     // entry staging; its first NW*RADIX 8-byte words double as the match masks (below)
     __shared__ __attribute__((aligned(16))) ET sent[TILE];
     __shared__ uint8_t saux[NARROW ? TILE : 4];  // narrow: pass 0 the partition digit, pass 1 the byte that replaces it
@@ -446,7 +454,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
     uint32_t rhint = 0;
     TilePf pf;
     if (FROM_BASES) {
-        pf = tile_fetch<true>(a, t0);
+        pf = tile_fetch<!YKEYS>(a, t0);
     } else {
         if constexpr (NARROW) {
             for (uint32_t i = tid; i <= RADIX; i += NT) sreg[i] = regions[i];
@@ -474,8 +482,8 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
             smask[i] = 0ull;  // the match masks must start (and, by construction, end) a tile all zero
         }
         if (FROM_BASES) {
-            tile_commit<true>(L, pf, stmp);
-            if (tile + 1 < t1) pf = tile_fetch<true>(a, tile + 1);
+            tile_commit<!YKEYS>(L, pf, stmp);
+            if (tile + 1 < t1) pf = tile_fetch<!YKEYS>(a, tile + 1);
         } else {
             lds_sync();
         }
@@ -496,7 +504,13 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
                 const uint32_t o = wl + j * 64;
                 uint32_t key;
                 ok = window_at(L, o, a.K, key);
-                uint32_t col = record_at(L, o);
+                uint32_t col;
+                if constexpr (YKEYS) {
+                    col = key & ((1u << a.low_bits) - 1u);
+                    key >>= a.low_bits;
+                } else {
+                    col = record_at(L, o);
+                }
                 asm volatile("" : "+v"(col));  // finish the column now: sunk to its use it keeps 4 LDS words per round alive
                 if constexpr (NARROW) {
                     d = key & 255u;
@@ -610,6 +624,95 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
         KK_STAMP(7);  // end barrier
     }
     KK_STAMP_END(FROM_BASES ? 0 : 8);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// y for K >= 9: histogram of partitioned k-mers
+// ------------------------------------------------------------------------------------------------------
+//
+// 4^K bins do not fit in LDS and scattered global atomics run at ~2e10/s whatever the working set
+// (tools/mb_atomics.hip), so the windows are first partitioned by the top 8 (K <= 12) or 16 (K >= 13) bits of the
+// k-mer id -- the narrow-entry passes of the X path with "column" = the low bits of the id -- and then every
+// workgroup owns a slice of 2^BPB_LOG2 consecutive bins: it finds the entries of its slice (they are contiguous),
+// counts them in LDS and adds the slice to `counts` with plain coalesced read-modify-writes (no other workgroup of
+// the launch touches those bins).
+//   entries: one pass   v = low bits                       sort key = region
+//            two passes v = (sort key & 255) << 24 | low   sort key = region << 8 | v >> 24
+
+// First index in [lo, hi) whose entry's top byte is >= c (hi if none); the range is sorted by that byte.
+// One wave, all 64 lanes; 64 probes per step.
+__device__ __forceinline__ uint32_t wave_lower_bound_byte(const uint32_t *ent, uint32_t lo, uint32_t hi, uint32_t c) {
+    const uint32_t lane = lane_id();
+    while (hi - lo > 64u) {
+        const uint32_t step = (hi - lo + 63u) / 64u;
+        const uint64_t p = (uint64_t)lo + (uint64_t)lane * step;
+        const bool ge = (p < hi) ? ((ent[p] >> 24) >= c) : true;
+        const u64 m = __ballot(ge);
+        const uint32_t f = m ? (uint32_t)__ffsll((long long)m) - 1u : 64u;  // first probe that is >= c
+        if (f == 0) return lo;
+        const uint64_t nhi = (uint64_t)lo + (uint64_t)f * step;  // f == 64: beyond hi
+        lo = lo + (f - 1u) * step + 1u;                           // probe f-1 is < c
+        if (nhi < hi) hi = (uint32_t)nhi;
+    }
+    const uint32_t p = lo + lane;
+    const bool ge = (p < hi) ? ((ent[p] >> 24) >= c) : true;
+    const u64 m = __ballot(ge);
+    const uint32_t f = m ? (uint32_t)__ffsll((long long)m) - 1u : 64u;
+    return (lo + f < hi) ? lo + f : hi;
+}
+
+constexpr int YS_NT = 1024, YS_UNROLL = 8;
+
+template <int BPB_LOG2>
+__global__ __launch_bounds__(YS_NT) void k_count_y_sorted(const uint32_t *ent, const uint32_t *regions, int two_pass, int low_bits,
+                                                          int32_t *counts) {
+    constexpr uint32_t NB = 1u << BPB_LOG2;
+    __shared__ uint32_t h[NB];
+    __shared__ uint32_t s_range[2];
+    const uint32_t tid = threadIdx.x, w = tid >> 6;
+    const uint64_t bin0 = (uint64_t)blockIdx.x << BPB_LOG2;                  // first bin of this workgroup's slice
+    const uint32_t k_lo = (uint32_t)(bin0 >> low_bits);                       // its first sort key
+    const uint32_t nk = BPB_LOG2 >= low_bits ? 1u << (BPB_LOG2 - low_bits) : 1u;  // sort keys it covers (1: part of one)
+    const uint32_t low_mask = (1u << low_bits) - 1u;
+    const uint32_t sub0 = (uint32_t)bin0 & low_mask;                          // non-zero when the slice is part of a key
+    for (uint32_t i = tid; i < NB; i += YS_NT) h[i] = 0;
+    uint32_t c_lo = 0;
+    if (!two_pass) {  // host guarantees nk == 1: the slice is (part of) region k_lo
+        if (tid < 2) s_range[tid] = regions[k_lo + tid];
+    } else {
+        const uint32_t r = k_lo >> 8;
+        c_lo = k_lo & 255u;
+        const uint32_t rb = regions[r], re = regions[r + 1];
+        if (w == 0) {
+            const uint32_t b = wave_lower_bound_byte(ent, rb, re, c_lo);
+            if (lane_id() == 0) s_range[0] = b;
+        } else if (w == 1) {
+            const uint32_t c_hi = c_lo + nk;
+            const uint32_t e = (c_hi > 255u) ? re : wave_lower_bound_byte(ent, rb, re, c_hi);
+            if (lane_id() == 0) s_range[1] = e;
+        }
+    }
+    lds_sync();
+    const uint32_t begin = s_range[0], end = s_range[1];
+    for (uint64_t i0 = (uint64_t)begin + tid; i0 < end; i0 += (uint64_t)YS_NT * YS_UNROLL) {
+        uint32_t v[YS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < YS_UNROLL; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * YS_NT;
+            v[u] = (i < end) ? ent[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < YS_UNROLL; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * YS_NT;
+            const uint32_t lb = ((((v[u] >> 24) - c_lo) << low_bits) | (v[u] & low_mask)) - sub0;
+            if (i < end && lb < NB) atomicAdd(&h[lb], 1u);
+        }
+    }
+    lds_sync();
+    for (uint32_t i = tid; i < NB; i += YS_NT) {
+        const uint32_t c = h[i];
+        if (c) counts[bin0 + i] += (int32_t)c;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1084,20 +1187,160 @@ static int scan_u32(const uint32_t *in, uint64_t n, uint32_t *out, uint32_t *blo
     return 0;
 }
 
-int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words, uint64_t n_pos, int K,
-            int32_t *d_counts, hipStream_t s) {
-    if (n_pos == 0) return 0;
-    BasesArgs a{d_bases, d_valid, nullptr, nullptr, bases_words, valid_words, n_pos, K};
+// ---- y workspace (K >= 9): entries of one chunk of tiles, the tile histogram and its scan, regions, scalars
+constexpr uint64_t Y_CHUNK_MAX_TILES = (1ull << 31) / TILE;  // entry indices stay far below 2^32
+
+struct YLayout {
+    uint32_t chunk_tiles;
+    uint64_t hist_len;
+    uint32_t scan_blocks;
+    int n_buf;
+    size_t off_entA, off_entB, off_hist, off_blocksums, off_scalars, off_regions, bytes;
+};
+
+static YLayout y_layout_for(uint32_t chunk_tiles, int K) {
+    YLayout l;
+    l.chunk_tiles = chunk_tiles;
+    l.hist_len = (uint64_t)RADIX * chunk_tiles;
+    l.scan_blocks = (uint32_t)((l.hist_len + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    l.n_buf = (K >= 13) ? 2 : 1;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = o;
+        o = align_up(o + bytes, 256);
+        return at;
+    };
+    const size_t ent = (size_t)chunk_tiles * TILE * 4;
+    l.off_entA = take(ent);
+    l.off_entB = take(l.n_buf == 2 ? ent : 0);
+    l.off_hist = take(l.hist_len * 4);
+    l.off_blocksums = take((size_t)l.scan_blocks * 4 + 4);
+    l.off_scalars = take(64);
+    l.off_regions = take(2 * (RADIX + 1) * 4);
+    l.bytes = o;
+    return l;
+}
+
+// Chunks of equal size, the fewest that respect Y_CHUNK_MAX_TILES.
+static uint32_t y_default_chunk_tiles(uint64_t n_pos) {
     const uint64_t n_tiles = (n_pos + TILE - 1) / TILE;
+    if (n_tiles == 0) return 1;
+    const uint64_t n_chunks = (n_tiles + Y_CHUNK_MAX_TILES - 1) / Y_CHUNK_MAX_TILES;
+    return (uint32_t)((n_tiles + n_chunks - 1) / n_chunks);
+}
+
+size_t y_workspace_bytes(uint64_t n_pos, int K) {
+    if (K <= 8 || n_pos == 0) return 0;
+    return y_layout_for(y_default_chunk_tiles(n_pos), K).bytes;
+}
+
+template <int BPB_LOG2>
+static void launch_y_sorted(uint32_t blocks, hipStream_t s, const uint32_t *ent, const uint32_t *regions, int two_pass, int low_bits,
+                            int32_t *counts) {
+    hipLaunchKernelGGL(k_count_y_sorted<BPB_LOG2>, dim3(blocks), dim3(YS_NT), 0, s, ent, regions, two_pass, low_bits, counts);
+}
+
+int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words, uint64_t n_pos, int K,
+            int32_t *d_counts, void *d_ws, size_t ws_bytes, hipStream_t s) {
+    if (n_pos == 0) return 0;
+    BasesArgs a{d_bases, d_valid, nullptr, nullptr, bases_words, valid_words, n_pos, K, 0, 0};
+    const uint64_t n_tiles = (n_pos + TILE - 1) / TILE;
+    PhaseTimer pt(s);
     if (K <= 8) {
         const uint32_t n_bins = 1u << (2 * K);
         const uint32_t grid = (uint32_t)(n_tiles < 256 ? n_tiles : 256);  // 128 KiB of LDS: one workgroup per CU
         hipLaunchKernelGGL(k_count_y_lds, dim3(grid), dim3(NT), 0, s, a, d_counts, n_tiles, n_bins);
-    } else {
+        pt.mark("k_count_y_lds");
+        KK_CHECK(hipGetLastError());
+        if (pt.on) {
+            KK_CHECK(hipStreamSynchronize(s));
+            pt.finish();
+        }
+        return 0;
+    }
+    if (getenv("KMERS_Y_ATOMICS")) {  // env: A-B runs against the plain global-atomics kernel
         const uint32_t grid = (uint32_t)(n_tiles < 2048 ? n_tiles : 2048);
         hipLaunchKernelGGL(k_count_y_global, dim3(grid), dim3(NT), 0, s, a, d_counts, n_tiles);
+        pt.mark("k_count_y_global");
+        KK_CHECK(hipGetLastError());
+        if (pt.on) {
+            KK_CHECK(hipStreamSynchronize(s));
+            pt.finish();
+        }
+        return 0;
+    }
+    // ---- K >= 9: partition by the top 8 / 16 bits of the id, then per-slice LDS histograms
+    const bool two_pass = K >= 13;
+    const int low_bits = 2 * K - (two_pass ? 16 : 8);          // 10..16
+    // slices: one pass -> at most one region each (10, 12, 14 -> whole region; 16 -> half); two passes -> 2^15 bins
+    const int slice_log2 = two_pass ? 15 : (low_bits < 15 ? low_bits : 15);
+    uint32_t chunk_tiles = y_default_chunk_tiles(n_pos);
+    if (!d_ws) return -14;
+    if (ws_bytes < y_layout_for(chunk_tiles, K).bytes) {
+        // a smaller workspace is fine: more, smaller chunks (bytes are monotone in the chunk size)
+        uint32_t lo = 0, hi = chunk_tiles;  // largest chunk that fits
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo + 1) / 2;
+            if (y_layout_for(mid, K).bytes <= ws_bytes)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        if (lo == 0) return -14;
+        chunk_tiles = lo;
+    }
+    const YLayout l = y_layout_for(chunk_tiles, K);
+    char *ws = (char *)d_ws;
+    uint32_t *entA = (uint32_t *)(ws + l.off_entA), *entB = (uint32_t *)(ws + l.off_entB);
+    uint32_t *hist = (uint32_t *)(ws + l.off_hist), *bsum = (uint32_t *)(ws + l.off_blocksums);
+    uint32_t *scal = (uint32_t *)(ws + l.off_scalars);  // [0] = E  [4] = dummy total
+    uint32_t *regs0 = (uint32_t *)(ws + l.off_regions), *regs1 = regs0 + (RADIX + 1);
+    const dim3 block(NT);
+    const uint32_t slices = (uint32_t)((1ull << (2 * K)) >> slice_log2);
+    for (uint64_t t0 = 0; t0 < n_tiles; t0 += chunk_tiles) {
+        const uint32_t nt = (uint32_t)((n_tiles - t0 < chunk_tiles) ? n_tiles - t0 : chunk_tiles);
+        const uint64_t hist_len = (uint64_t)RADIX * nt;
+        const uint32_t scan_blocks = (uint32_t)((hist_len + SCAN_CHUNK - 1) / SCAN_CHUNK);
+        a.tile0 = t0;
+        a.low_bits = low_bits;
+        const dim3 grid(nt);
+        const dim3 pgrid(nt < (uint32_t)PERSIST_BLOCKS ? nt : (uint32_t)PERSIST_BLOCKS);
+        const dim3 hgrid(nt < 2048u ? nt : 2048u);
+        const uint32_t *c_hist = hist, *c_E = &scal[0];
+        hipLaunchKernelGGL(k_hist_bases<true>, hgrid, block, 0, s, a, hist, nt, (uint32_t *)nullptr);
+        pt.mark("k_hist_bases<y>");
+        if (int rc = scan_u32(hist, hist_len, hist, bsum, scan_blocks, &scal[0], s)) return rc;
+        pt.mark("k_scan");
+        hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, nt, c_E, regs0);
+        hipLaunchKernelGGL((k_scatter<true, uint32_t, true>), pgrid, block, 0, s, a, (const uint32_t *)nullptr, c_E, 0, c_hist, nt, entA,
+                           (const uint32_t *)nullptr);
+        pt.mark("k_scatter<bases,y>");
+        const uint32_t *sorted = entA, *final_regions = regs0;
+        if (two_pass) {
+            hipLaunchKernelGGL(k_hist_entries<uint32_t>, grid, block, 0, s, (const uint32_t *)entA, c_E, 8, hist, nt);
+            pt.mark("k_hist_entries");
+            if (int rc = scan_u32(hist, hist_len, hist, bsum, scan_blocks, &scal[4], s)) return rc;
+            pt.mark("k_scan");
+            hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, nt, c_E, regs1);
+            hipLaunchKernelGGL((k_scatter<false, uint32_t>), pgrid, block, 0, s, a, (const uint32_t *)entA, c_E, 8, c_hist, nt, entB,
+                               (const uint32_t *)regs0);
+            pt.mark("k_scatter<entries>");
+            sorted = entB;
+            final_regions = regs1;
+        }
+        switch (slice_log2) {
+            case 10: launch_y_sorted<10>(slices, s, sorted, final_regions, two_pass, low_bits, d_counts); break;
+            case 12: launch_y_sorted<12>(slices, s, sorted, final_regions, two_pass, low_bits, d_counts); break;
+            case 14: launch_y_sorted<14>(slices, s, sorted, final_regions, two_pass, low_bits, d_counts); break;
+            default: launch_y_sorted<15>(slices, s, sorted, final_regions, two_pass, low_bits, d_counts); break;
+        }
+        pt.mark("k_count_y_sorted");
     }
     KK_CHECK(hipGetLastError());
+    if (pt.on) {  // per-kernel timing needs the events completed
+        KK_CHECK(hipStreamSynchronize(s));
+        pt.finish();
+    }
     return 0;
 }
 
@@ -1146,7 +1389,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     const uint32_t *c_hist = hist, *c_E = &scal[0];
 
     // pass 0: packed bases -> instances partitioned by the lowest digit
-    hipLaunchKernelGGL(k_hist_bases, hgrid, block, 0, s, a, hist, l.n_tiles, total);
+    hipLaunchKernelGGL(k_hist_bases<false>, hgrid, block, 0, s, a, hist, l.n_tiles, total);
     pt.mark("k_hist_bases");
     if (int rc = scan_u32(hist, l.hist_len, hist, bsum, l.scan_blocks, &scal[0], s)) return rc;
     pt.mark("k_scan");

@@ -21,9 +21,12 @@ int read_stamps(unsigned long long *out16, bool reset);  // diagnostic builds (-
 
 size_t x_workspace_bytes(uint64_t n_pos, uint64_t n_rec, int K);
 
-// Both return 0 or a KMERS_ERR_* code (include/kmers_hip.h).
+size_t y_workspace_bytes(uint64_t n_pos, int K);  // 0 for K <= 8
+
+// Both return 0 or a KMERS_ERR_* code (include/kmers_hip.h).  count_y needs a workspace for K >= 9 (any size from one
+// tile's worth up: a smaller one means more chunks).
 int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words, uint64_t n_pos, int K,
-            int32_t *d_counts, hipStream_t s);
+            int32_t *d_counts, void *d_ws, size_t ws_bytes, hipStream_t s);
 
 int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words, const uint64_t *d_rec_start,
             uint64_t n_pos, uint64_t n_rec, uint64_t first_col, int K, float *d_data, uint64_t *d_col_ind, uint64_t *d_row_ind,

@@ -107,8 +107,11 @@ int count_files(int n_files, const char *fnames[], int K, int *counts, int mode)
     DevBuf dc;
     API_HIP(dc.alloc(M * 4));
     API_HIP(hipMemsetAsync(dc.p, 0, M * 4, s));
+    DevBuf d_ws;
+    const size_t ws_bytes = kk::y_workspace_bytes(n_pos, K);
+    if (ws_bytes) API_HIP(d_ws.alloc(ws_bytes));
     if (int rc = kk::count_y(ds.bases.as<uint32_t>(), st->bases_words, ds.valid.as<uint32_t>(), st->valid_words, n_pos, K,
-                             dc.as<int32_t>(), s))
+                             dc.as<int32_t>(), d_ws.p, ws_bytes, s))
         return rc;
     // the reference only ever increments the caller's array (src/libkmers.cpp:213-216): add, do not overwrite
     std::unique_ptr<int32_t[]> h(new (std::nothrow) int32_t[M]);
@@ -217,7 +220,28 @@ int kmers_hip_count_y(const uint32_t *d_bases, size_t bases_words, const uint32_
                       int K, int32_t *d_counts, void *stream) {
     if (K < 1 || K > 16 || !d_counts || (n_pos && (!d_bases || !d_valid))) return KMERS_ERR_BAD_ARG;
     if (bases_words < (n_pos + 15) / 16 || valid_words < (n_pos + 31) / 32) return KMERS_ERR_BAD_ARG;
-    return kk::count_y(d_bases, bases_words, d_valid, valid_words, n_pos, K, d_counts, (hipStream_t)stream);
+    const size_t ws_bytes = kk::y_workspace_bytes(n_pos, K);
+    if (!ws_bytes) return kk::count_y(d_bases, bases_words, d_valid, valid_words, n_pos, K, d_counts, nullptr, 0, (hipStream_t)stream);
+    // K >= 9 works in a scratch buffer: this call owns one for its duration, so it has to wait for the stream
+    DevBuf d_ws;
+    API_HIP(d_ws.alloc(ws_bytes));
+    const int rc = kk::count_y(d_bases, bases_words, d_valid, valid_words, n_pos, K, d_counts, d_ws.p, ws_bytes, (hipStream_t)stream);
+    API_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return rc;
+}
+
+size_t kmers_hip_y_workspace_bytes(uint64_t n_pos, int K) {
+    if (K < 1 || K > 16) return 0;
+    return kk::y_workspace_bytes(n_pos, K);
+}
+
+int kmers_hip_count_y_ws(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words, uint64_t n_pos,
+                         int K, int32_t *d_counts, void *d_workspace, size_t workspace_bytes, void *stream) {
+    if (K < 1 || K > 16 || !d_counts || (n_pos && (!d_bases || !d_valid))) return KMERS_ERR_BAD_ARG;
+    if (bases_words < (n_pos + 15) / 16 || valid_words < (n_pos + 31) / 32) return KMERS_ERR_BAD_ARG;
+    if (K >= 9 && n_pos && !d_workspace) return KMERS_ERR_WORKSPACE;
+    return kk::count_y(d_bases, bases_words, d_valid, valid_words, n_pos, K, d_counts, d_workspace, workspace_bytes,
+                       (hipStream_t)stream);
 }
 
 size_t kmers_hip_x_workspace_bytes(uint64_t n_pos, uint64_t n_rec, int K) {

@@ -86,16 +86,27 @@ class DeviceStore:
         self.valid = torch.from_numpy(store.valid.view(np.int32).copy()).to(self.device)
         self.rec_start = torch.from_numpy(store.rec_start.view(np.int64).copy()).to(self.device)
 
-    def count_y(self, K, counts=None, stream=None):
-        """counts (int32[4**K] on the device) += histogram of this store.  Asynchronous."""
+    def y_workspace(self, K, nbytes=None):
+        """Scratch for count_y at K >= 9 (None for K <= 8); keep it across repeated counts."""
+        import torch
+        if nbytes is None:
+            nbytes = int(self._lib.kmers_hip_y_workspace_bytes(self.n_pos, K))
+        return torch.empty(nbytes, dtype=torch.uint8, device=self.device) if nbytes else None
+
+    def count_y(self, K, counts=None, stream=None, workspace=None):
+        """counts (int32[4**K] on the device) += histogram of this store.  Asynchronous; K >= 9 works in `workspace`
+        (from y_workspace; allocated here when not given)."""
         import torch
         if counts is None:
             counts = torch.zeros(4 ** K, dtype=torch.int32, device=self.device)
         assert counts.dtype == torch.int32 and counts.numel() == 4 ** K and counts.is_contiguous()
-        rc = self._lib.kmers_hip_count_y(self.bases.data_ptr(), self.bases.numel(), self.valid.data_ptr(),
-                                         self.valid.numel(), self.n_pos, K, counts.data_ptr(),
-                                         _stream_ptr(stream))
-        _lib.check(rc, "kmers_hip_count_y")
+        if workspace is None:
+            workspace = self.y_workspace(K)
+        rc = self._lib.kmers_hip_count_y_ws(self.bases.data_ptr(), self.bases.numel(), self.valid.data_ptr(),
+                                            self.valid.numel(), self.n_pos, K, counts.data_ptr(),
+                                            workspace.data_ptr() if workspace is not None else None,
+                                            workspace.numel() if workspace is not None else 0, _stream_ptr(stream))
+        _lib.check(rc, "kmers_hip_count_y_ws")
         return counts
 
     def x_buffers(self, K, max_nz):

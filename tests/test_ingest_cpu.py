@@ -116,7 +116,8 @@ def test_scalars_and_exports(product):
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names |= set(re.findall(r"\b(k?mers?_\w+|kmer_to_id|valid_kmer|fast[aq]\w+)\s*\(", src))
     assert {"kmer_to_id", "valid_kmer", "fasta_count_kmers", "fastq_gz_count_kmers", "fasta_to_kmers_csr",
-            "fasta_to_kmers_csr_cat_subseq", "kmers_hip_build_x", "kmers_hip_count_y"} <= names
+            "fasta_to_kmers_csr_cat_subseq", "kmers_hip_build_x", "kmers_hip_count_y", "kmers_hip_count_y_ws",
+            "kmers_hip_y_workspace_bytes"} <= names
     for n in names:
         assert hasattr(lib, n), n
 

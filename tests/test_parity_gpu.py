@@ -64,13 +64,58 @@ def test_x_variants_vs_oracle(product, oracle, syn, K, L, cat):
     kmtest.assert_x_equal(product.x(files, K, L, cat), oracle.x(files, K, L, cat))
 
 
-@pytest.mark.parametrize("K", [1, 3, 6, 7, 8, 10, 12, 14])
+@pytest.mark.parametrize("K", [1, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14])
 def test_y_random_vs_oracle(product, oracle, syn, K):
     rc, y = product.y([syn["reads"], syn["uni"]], K)
     rc2, y2 = oracle.y([syn["reads"], syn["uni"]], K)
     assert rc == rc2 == 0
     assert int(y.sum()) > 0
     assert np.array_equal(y, y2)
+
+
+@pytest.mark.parametrize("K", [9, 12, 13, 14])
+def test_y_small_workspace_chunks(oracle, syn, K):
+    """kmers_hip_count_y_ws with a scratch buffer far smaller than recommended: the store is counted in several
+    chunks of tiles (windows that span a chunk boundary included) and the histogram is the same."""
+    import torch
+    from kmers_amd.store import MODE_Y_FASTA, Store
+    rc, want = oracle.y([syn["reads"]], K)
+    assert rc == 0
+    st = Store(syn["reads"], MODE_Y_FASTA)
+    ds = st.to_device()
+    full = ds._lib.kmers_hip_y_workspace_bytes(st.n_pos, K)
+    assert st.n_pos > 20 * 8192
+    for nbytes in (full, full // 7, 5 * 8192 * 8):          # one chunk, ~7 chunks, chunks of a few tiles
+        ws = ds.y_workspace(K, nbytes)
+        got = ds.count_y(K, workspace=ws)
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy(), want), nbytes
+    with pytest.raises(RuntimeError):
+        ds.count_y(K, workspace=ds.y_workspace(K, 4096))    # not even one tile
+
+
+@pytest.mark.parametrize("K", [15, 16])
+def test_y_largest_k_partition_equals_atomics(syn, K, monkeypatch):
+    """K = 15, 16 (4 / 16 GiB of bins: no oracle run at that size): the partition path against the plain
+    global-atomics kernel on the GPU, plus the total against the host-side window count."""
+    import torch
+    from kmers_amd.store import MODE_Y_FASTA, Store
+    st = Store(syn["reads"], MODE_Y_FASTA)
+    ds = st.to_device()
+    a = ds.count_y(K)
+    monkeypatch.setenv("KMERS_Y_ATOMICS", "1")
+    b = ds.count_y(K)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    total = int(a.sum(dtype=torch.int64).item())
+    assert 0 < total <= st.n_windows(K)
+    if K == 16:
+        return
+    # every bin index decodes to a k-mer that occurs: spot-check the heaviest bin against a host count at K=15
+    top = int(torch.argmax(a).item())
+    kmer = "".join("ACGT"[(top >> (2 * (K - 1 - i))) & 3] for i in range(K)).encode()
+    n = sum(sum(1 for i in range(len(seq) - K + 1) if seq[i:i + K] == kmer) for seq in st.sequences())
+    assert n == int(a[top].item())
 
 
 def test_y_accumulates_into_callers_buffer(product, syn):
