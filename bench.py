@@ -34,13 +34,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="x8", choices=["x8", "x12", "x14", "y8", "y12", "y14"])
+    ap.add_argument("--workload", default="x8", help="x<K> or y<K>, K in 1..16 (x8, x14, y12 are BASELINE.json's)")
     ap.add_argument("--records", type=int, default=170_000)
     ap.add_argument("--bases", type=int, default=400_000_000)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU for the y workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cache", default=os.environ.get("KMERS_BENCH_CACHE", "/tmp/kmers_bench"))
-    return ap.parse_args()
+    args = ap.parse_args()
+    import re
+    if not re.fullmatch(r"[xy]([1-9]|1[0-6])", args.workload):
+        ap.error("--workload must be x<K> or y<K> with K in 1..16")
+    return args
 
 
 def make_inputs(args, rank, want_reads):

@@ -661,57 +661,164 @@ __device__ __forceinline__ uint32_t wave_lower_bound_byte(const uint32_t *ent, u
     return (lo + f < hi) ? lo + f : hi;
 }
 
-constexpr int YS_NT = 1024, YS_UNROLL = 8;
+constexpr int YS_NT = 1024, YS_UNROLL = 4;
+constexpr uint32_t YS_OVF_CHUNK = 1u << 18;  // entries per workgroup pass in the overflow kernel
 
+// What a slice's bins are: everything needed to turn an entry into a bin of the slice's LDS table.
+struct YSlice {
+    uint64_t bin0;      // first bin of the slice
+    uint32_t k_lo, nk;  // first sort key of the slice / sort keys it covers (1: the slice is part of one key)
+    uint32_t c_lo;      // two passes: top byte of the first entry value of the slice
+    uint32_t low_mask, sub0;
+    int low_bits;
+};
+template <int BPB_LOG2>
+__device__ __forceinline__ YSlice ys_slice(uint32_t slice, int two_pass, int low_bits) {
+    YSlice y;
+    y.bin0 = (uint64_t)slice << BPB_LOG2;
+    y.k_lo = (uint32_t)(y.bin0 >> low_bits);
+    y.nk = BPB_LOG2 >= low_bits ? 1u << (BPB_LOG2 - low_bits) : 1u;
+    y.low_mask = (1u << low_bits) - 1u;
+    y.sub0 = (uint32_t)y.bin0 & y.low_mask;  // non-zero when the slice is part of a key
+    y.c_lo = two_pass ? (y.k_lo & 255u) : 0u;
+    y.low_bits = low_bits;
+    return y;
+}
+
+// h[bin] += 1 for every lane whose bin is < NB -- but equal bins in consecutive lanes are added once, with the run
+// length: reads are full of homopolymer runs (poly-A tails: 0.7 % of the bench's windows are one k-mer), and 64
+// same-address LDS atomics serialise.  ALL 64 lanes must call it (lanes without an entry pass NONE).
+template <uint32_t NB>
+__device__ __forceinline__ void ys_add(uint32_t *h, uint32_t bin) {
+    const uint32_t key = bin < NB ? bin : NONE;
+    // previous lane's key (wave_shr:1); lane 0 keeps `old` = ~key, which differs from key
+    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x138, 0xF, 0xF, false);
+    const bool head = key != prev;
+    const u64 hm = __ballot(head);
+    if (head && key != NONE) {
+        const uint32_t lane = lane_id();
+        const u64 above = (hm >> lane) >> 1;  // heads in the lanes after this one
+        const uint32_t len = above ? (uint32_t)__ffsll((long long)above) : 64u - lane;
+        atomicAdd(&h[key], len);
+    }
+}
+
+// Count entries [begin, end) into h.  All YS_NT threads call it with the same arguments.
+template <uint32_t NB>
+__device__ __forceinline__ void ys_count_range(uint32_t *h, const uint32_t *ent, uint32_t begin, uint32_t end, const YSlice &y) {
+    const uint32_t tid = threadIdx.x;
+    auto bin_of = [&](uint32_t v) { return ((((v >> 24) - y.c_lo) << y.low_bits) | (v & y.low_mask)) - y.sub0; };
+    // 16-byte loads over the aligned body, YS_UNROLL of them in flight per lane; the ragged ends one entry at a time
+    const uint32_t a0 = (begin + 3u) & ~3u, a1 = end & ~3u;
+    if (a0 < a1) {
+        ys_add<NB>(h, (begin + tid < a0) ? bin_of(ent[begin + tid]) : NONE);
+        ys_add<NB>(h, (a1 + tid < end) ? bin_of(ent[a1 + tid]) : NONE);
+        const uint4 *ent4 = reinterpret_cast<const uint4 *>(ent);
+        const uint32_t q1 = a1 >> 2;
+        for (uint32_t qb = a0 >> 2; qb < q1; qb += YS_NT * YS_UNROLL) {  // wave-uniform trip count
+            uint4 v[YS_UNROLL];
+#pragma unroll
+            for (int u = 0; u < YS_UNROLL; ++u) {
+                const uint32_t q = qb + u * YS_NT + tid;
+                v[u] = (q < q1) ? ent4[q] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < YS_UNROLL; ++u) {
+                const bool in = qb + u * YS_NT + tid < q1;
+                ys_add<NB>(h, in ? bin_of(v[u].x) : NONE);
+                ys_add<NB>(h, in ? bin_of(v[u].y) : NONE);
+                ys_add<NB>(h, in ? bin_of(v[u].z) : NONE);
+                ys_add<NB>(h, in ? bin_of(v[u].w) : NONE);
+            }
+        }
+    } else {
+        for (uint32_t ib = begin; ib < end; ib += YS_NT) ys_add<NB>(h, (ib + tid < end) ? bin_of(ent[ib + tid]) : NONE);
+    }
+}
+
+struct YOverflow {
+    uint32_t slice, begin, end, pad;
+};
+
+// One workgroup per slice.  A slice with more than `cap` entries (a hot bucket: poly-A) keeps its first `cap` and
+// queues the rest for k_count_y_overflow, which spreads it over many workgroups.
 template <int BPB_LOG2>
 __global__ __launch_bounds__(YS_NT) void k_count_y_sorted(const uint32_t *ent, const uint32_t *regions, int two_pass, int low_bits,
-                                                          int32_t *counts) {
+                                                          int32_t *counts, uint32_t cap, uint32_t *ovf_count, YOverflow *ovf,
+                                                          uint32_t ovf_cap) {
     constexpr uint32_t NB = 1u << BPB_LOG2;
     __shared__ uint32_t h[NB];
     __shared__ uint32_t s_range[2];
     const uint32_t tid = threadIdx.x, w = tid >> 6;
-    const uint64_t bin0 = (uint64_t)blockIdx.x << BPB_LOG2;                  // first bin of this workgroup's slice
-    const uint32_t k_lo = (uint32_t)(bin0 >> low_bits);                       // its first sort key
-    const uint32_t nk = BPB_LOG2 >= low_bits ? 1u << (BPB_LOG2 - low_bits) : 1u;  // sort keys it covers (1: part of one)
-    const uint32_t low_mask = (1u << low_bits) - 1u;
-    const uint32_t sub0 = (uint32_t)bin0 & low_mask;                          // non-zero when the slice is part of a key
+    const YSlice y = ys_slice<BPB_LOG2>(blockIdx.x, two_pass, low_bits);
     for (uint32_t i = tid; i < NB; i += YS_NT) h[i] = 0;
-    uint32_t c_lo = 0;
     if (!two_pass) {  // host guarantees nk == 1: the slice is (part of) region k_lo
-        if (tid < 2) s_range[tid] = regions[k_lo + tid];
+        if (tid < 2) s_range[tid] = regions[y.k_lo + tid];
     } else {
-        const uint32_t r = k_lo >> 8;
-        c_lo = k_lo & 255u;
+        const uint32_t r = y.k_lo >> 8;
         const uint32_t rb = regions[r], re = regions[r + 1];
         if (w == 0) {
-            const uint32_t b = wave_lower_bound_byte(ent, rb, re, c_lo);
+            const uint32_t b = wave_lower_bound_byte(ent, rb, re, y.c_lo);
             if (lane_id() == 0) s_range[0] = b;
         } else if (w == 1) {
-            const uint32_t c_hi = c_lo + nk;
+            const uint32_t c_hi = y.c_lo + y.nk;
             const uint32_t e = (c_hi > 255u) ? re : wave_lower_bound_byte(ent, rb, re, c_hi);
             if (lane_id() == 0) s_range[1] = e;
         }
     }
     lds_sync();
-    const uint32_t begin = s_range[0], end = s_range[1];
-    for (uint64_t i0 = (uint64_t)begin + tid; i0 < end; i0 += (uint64_t)YS_NT * YS_UNROLL) {
-        uint32_t v[YS_UNROLL];
-#pragma unroll
-        for (int u = 0; u < YS_UNROLL; ++u) {
-            const uint64_t i = i0 + (uint64_t)u * YS_NT;
-            v[u] = (i < end) ? ent[i] : 0u;
+    const uint32_t begin = s_range[0];
+    uint32_t end = s_range[1];
+    lds_sync();
+    if (end - begin > cap) {  // workgroup-uniform
+        if (tid == 0) {
+            const uint32_t idx = atomicAdd(ovf_count, 1u);
+            if (idx < ovf_cap) {
+                ovf[idx] = YOverflow{blockIdx.x, begin + cap, end, 0u};
+                s_range[1] = begin + cap;
+            }  // (a full queue cannot happen -- it holds every slice that can exceed cap -- but then: do it all here)
         }
-#pragma unroll
-        for (int u = 0; u < YS_UNROLL; ++u) {
-            const uint64_t i = i0 + (uint64_t)u * YS_NT;
-            const uint32_t lb = ((((v[u] >> 24) - c_lo) << low_bits) | (v[u] & low_mask)) - sub0;
-            if (i < end && lb < NB) atomicAdd(&h[lb], 1u);
-        }
+        lds_sync();
+        end = s_range[1];
     }
+    ys_count_range<NB>(h, ent, begin, end, y);
     lds_sync();
     for (uint32_t i = tid; i < NB; i += YS_NT) {
         const uint32_t c = h[i];
-        if (c) counts[bin0 + i] += (int32_t)c;
+        if (c) counts[y.bin0 + i] += (int32_t)c;  // this launch's only writer of these bins
+    }
+}
+
+// The queued remainders, YS_OVF_CHUNK entries per workgroup pass, chunks dealt round-robin over the grid; these
+// share their bins with other workgroups, so they add to `counts` with atomics (non-zero bins only).
+template <int BPB_LOG2>
+__global__ __launch_bounds__(YS_NT) void k_count_y_overflow(const uint32_t *ent, int two_pass, int low_bits, int32_t *counts,
+                                                            const uint32_t *ovf_count, const YOverflow *ovf, uint32_t ovf_cap) {
+    constexpr uint32_t NB = 1u << BPB_LOG2;
+    __shared__ uint32_t h[NB];
+    const uint32_t tid = threadIdx.x;
+    uint32_t n = *ovf_count;
+    if (n > ovf_cap) n = ovf_cap;
+    uint32_t next = blockIdx.x;  // global index of this workgroup's next chunk
+    uint32_t base = 0;           // global index of the current item's first chunk
+    for (uint32_t i = 0; i < n; ++i) {
+        const YOverflow it = ovf[i];
+        const uint32_t nch = (it.end - it.begin + YS_OVF_CHUNK - 1) / YS_OVF_CHUNK;
+        const YSlice y = ys_slice<BPB_LOG2>(it.slice, two_pass, low_bits);
+        for (; next < base + nch; next += gridDim.x) {
+            const uint32_t b = it.begin + (next - base) * YS_OVF_CHUNK;
+            const uint32_t e = (it.end - b > YS_OVF_CHUNK) ? b + YS_OVF_CHUNK : it.end;
+            for (uint32_t j = tid; j < NB; j += YS_NT) h[j] = 0;
+            lds_sync();
+            ys_count_range<NB>(h, ent, b, e, y);
+            lds_sync();
+            for (uint32_t j = tid; j < NB; j += YS_NT) {
+                const uint32_t c = h[j];
+                if (c) atomicAdd(&counts[y.bin0 + j], (int32_t)c);
+            }
+            lds_sync();
+        }
+        base += nch;
     }
 }
 
@@ -1195,7 +1302,9 @@ struct YLayout {
     uint64_t hist_len;
     uint32_t scan_blocks;
     int n_buf;
-    size_t off_entA, off_entB, off_hist, off_blocksums, off_scalars, off_regions, bytes;
+    size_t off_entA, off_entB, off_hist, off_blocksums, off_scalars, off_regions, off_ovf, bytes;
+    int slice_log2;     // bins per workgroup of the final histogram kernel
+    uint32_t slices;    // 4^K >> slice_log2: also the capacity of the overflow queue
 };
 
 static YLayout y_layout_for(uint32_t chunk_tiles, int K) {
@@ -1204,6 +1313,11 @@ static YLayout y_layout_for(uint32_t chunk_tiles, int K) {
     l.hist_len = (uint64_t)RADIX * chunk_tiles;
     l.scan_blocks = (uint32_t)((l.hist_len + SCAN_CHUNK - 1) / SCAN_CHUNK);
     l.n_buf = (K >= 13) ? 2 : 1;
+    const int low_bits = 2 * K - (K >= 13 ? 16 : 8);  // 10..16
+    // one pass: a slice is at most one region (low_bits 10, 12, 14 -> the whole region, 16 -> half of it);
+    // two passes: 2^15 bins (2^(15 - low_bits) buckets, or half a bucket at K = 16)
+    l.slice_log2 = (K >= 13) ? 15 : (low_bits < 15 ? low_bits : 15);
+    l.slices = (uint32_t)((1ull << (2 * K)) >> l.slice_log2);
     size_t o = 0;
     auto take = [&](size_t bytes) {
         size_t at = o;
@@ -1217,6 +1331,7 @@ static YLayout y_layout_for(uint32_t chunk_tiles, int K) {
     l.off_blocksums = take((size_t)l.scan_blocks * 4 + 4);
     l.off_scalars = take(64);
     l.off_regions = take(2 * (RADIX + 1) * 4);
+    l.off_ovf = take((size_t)l.slices * sizeof(YOverflow));
     l.bytes = o;
     return l;
 }
@@ -1236,8 +1351,11 @@ size_t y_workspace_bytes(uint64_t n_pos, int K) {
 
 template <int BPB_LOG2>
 static void launch_y_sorted(uint32_t blocks, hipStream_t s, const uint32_t *ent, const uint32_t *regions, int two_pass, int low_bits,
-                            int32_t *counts) {
-    hipLaunchKernelGGL(k_count_y_sorted<BPB_LOG2>, dim3(blocks), dim3(YS_NT), 0, s, ent, regions, two_pass, low_bits, counts);
+                            int32_t *counts, uint32_t cap, uint32_t *ovf_count, YOverflow *ovf, uint32_t ovf_cap) {
+    hipLaunchKernelGGL(k_count_y_sorted<BPB_LOG2>, dim3(blocks), dim3(YS_NT), 0, s, ent, regions, two_pass, low_bits, counts, cap,
+                       ovf_count, ovf, ovf_cap);
+    hipLaunchKernelGGL(k_count_y_overflow<BPB_LOG2>, dim3(1024), dim3(YS_NT), 0, s, ent, two_pass, low_bits, counts,
+                       (const uint32_t *)ovf_count, (const YOverflow *)ovf, ovf_cap);
 }
 
 int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words, uint64_t n_pos, int K,
@@ -1272,8 +1390,6 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     // ---- K >= 9: partition by the top 8 / 16 bits of the id, then per-slice LDS histograms
     const bool two_pass = K >= 13;
     const int low_bits = 2 * K - (two_pass ? 16 : 8);          // 10..16
-    // slices: one pass -> at most one region each (10, 12, 14 -> whole region; 16 -> half); two passes -> 2^15 bins
-    const int slice_log2 = two_pass ? 15 : (low_bits < 15 ? low_bits : 15);
     uint32_t chunk_tiles = y_default_chunk_tiles(n_pos);
     if (!d_ws) return -14;
     if (ws_bytes < y_layout_for(chunk_tiles, K).bytes) {
@@ -1295,14 +1411,23 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     uint32_t *hist = (uint32_t *)(ws + l.off_hist), *bsum = (uint32_t *)(ws + l.off_blocksums);
     uint32_t *scal = (uint32_t *)(ws + l.off_scalars);  // [0] = E  [4] = dummy total
     uint32_t *regs0 = (uint32_t *)(ws + l.off_regions), *regs1 = regs0 + (RADIX + 1);
+    YOverflow *ovf = (YOverflow *)(ws + l.off_ovf);
     const dim3 block(NT);
-    const uint32_t slices = (uint32_t)((1ull << (2 * K)) >> slice_log2);
+    const uint32_t slices = l.slices;
+    // entry ranges the slices read: the 256 regions, or the slices' own bucket groups (at K = 16: the 65536 buckets)
+    const uint64_t n_ranges = two_pass ? (slices < 65536u ? slices : 65536u) : 256u;
     for (uint64_t t0 = 0; t0 < n_tiles; t0 += chunk_tiles) {
         const uint32_t nt = (uint32_t)((n_tiles - t0 < chunk_tiles) ? n_tiles - t0 : chunk_tiles);
         const uint64_t hist_len = (uint64_t)RADIX * nt;
         const uint32_t scan_blocks = (uint32_t)((hist_len + SCAN_CHUNK - 1) / SCAN_CHUNK);
         a.tile0 = t0;
         a.low_bits = low_bits;
+        KK_CHECK(hipMemsetAsync(scal, 0, 64, s));  // [8] = length of the overflow queue
+        // a slice's workgroup counts at most `cap` entries itself: twice the mean range, at least two overflow chunks
+        uint64_t cap64 = 2 * ((uint64_t)nt * TILE / n_ranges);
+        if (cap64 < 2 * (uint64_t)YS_OVF_CHUNK) cap64 = 2 * (uint64_t)YS_OVF_CHUNK;
+        if (const char *e = getenv("KMERS_Y_CAP")) cap64 = strtoull(e, nullptr, 10) ? strtoull(e, nullptr, 10) : 1;  // env: tests
+        const uint32_t cap = (uint32_t)(cap64 > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap64);
         const dim3 grid(nt);
         const dim3 pgrid(nt < (uint32_t)PERSIST_BLOCKS ? nt : (uint32_t)PERSIST_BLOCKS);
         const dim3 hgrid(nt < 2048u ? nt : 2048u);
@@ -1328,11 +1453,11 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
             sorted = entB;
             final_regions = regs1;
         }
-        switch (slice_log2) {
-            case 10: launch_y_sorted<10>(slices, s, sorted, final_regions, two_pass, low_bits, d_counts); break;
-            case 12: launch_y_sorted<12>(slices, s, sorted, final_regions, two_pass, low_bits, d_counts); break;
-            case 14: launch_y_sorted<14>(slices, s, sorted, final_regions, two_pass, low_bits, d_counts); break;
-            default: launch_y_sorted<15>(slices, s, sorted, final_regions, two_pass, low_bits, d_counts); break;
+        switch (l.slice_log2) {
+            case 10: launch_y_sorted<10>(slices, s, sorted, final_regions, two_pass, low_bits, d_counts, cap, &scal[8], ovf, slices); break;
+            case 12: launch_y_sorted<12>(slices, s, sorted, final_regions, two_pass, low_bits, d_counts, cap, &scal[8], ovf, slices); break;
+            case 14: launch_y_sorted<14>(slices, s, sorted, final_regions, two_pass, low_bits, d_counts, cap, &scal[8], ovf, slices); break;
+            default: launch_y_sorted<15>(slices, s, sorted, final_regions, two_pass, low_bits, d_counts, cap, &scal[8], ovf, slices); break;
         }
         pt.mark("k_count_y_sorted");
     }

@@ -94,6 +94,40 @@ def test_y_small_workspace_chunks(oracle, syn, K):
         ds.count_y(K, workspace=ds.y_workspace(K, 4096))    # not even one tile
 
 
+@pytest.mark.parametrize("K", [9, 12, 14, 16])
+def test_y_hot_bucket_overflow_queue(oracle, tmp_path, K, monkeypatch):
+    """A slice with more entries than the per-workgroup cap hands the rest to the overflow kernel (several chunks,
+    atomics into bins the slice's own workgroup also writes).  Poly-A reads put ~4e5 windows into one bin; the cap is
+    forced down so that ordinary slices overflow too."""
+    import torch
+    from kmers_amd.store import MODE_Y_FASTA, Store
+    rng = np.random.default_rng(K)
+    p = tmp_path / "hot.fsa"
+    with open(p, "wb") as f:
+        for i in range(6000):
+            seq = b"A" * 100 if i % 4 else bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 100))
+            f.write(b">r%d\n%s\n" % (i, seq))
+    st = Store(str(p), MODE_Y_FASTA)
+    ds = st.to_device()
+    if K <= 14:
+        rc, want = oracle.y([str(p)], K)
+        assert rc == 0
+        want = torch.from_numpy(want)
+    else:
+        monkeypatch.setenv("KMERS_Y_ATOMICS", "1")
+        want = ds.count_y(K).cpu()
+        monkeypatch.delenv("KMERS_Y_ATOMICS")
+    for cap in ("1000", "7", None):
+        if cap is None:
+            monkeypatch.delenv("KMERS_Y_CAP")
+        else:
+            monkeypatch.setenv("KMERS_Y_CAP", cap)
+        got = ds.count_y(K)
+        torch.cuda.synchronize()
+        assert torch.equal(got.cpu(), want), cap
+    assert int(want[0]) >= 4500 * (100 - K + 1)
+
+
 @pytest.mark.parametrize("K", [15, 16])
 def test_y_largest_k_partition_equals_atomics(syn, K, monkeypatch):
     """K = 15, 16 (4 / 16 GiB of bins: no oracle run at that size): the partition path against the plain
