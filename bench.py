@@ -79,7 +79,8 @@ def cpu_baseline(args, K, kind_x):
         lib, kind = kmtest.Lib(ref_so, ""), "reference"
     else:
         lib, kind, cores = kmtest.load_oracle(), "port", 1
-    n_rec, n_bases = max(100, args.records // 10), max(100_000, args.bases // 10)
+    frac = 4 if kind_x else 10          # ~20-40 core-seconds of the reference either way
+    n_rec, n_bases = max(100, args.records // frac), max(100_000, args.bases // frac)
     sample = os.path.join(args.cache, f"cpu_sample_r{n_rec}_b{n_bases}.fsa")
     info = None
     if not os.path.exists(sample):
