@@ -40,6 +40,12 @@ constexpr int NW = NT / 64;      // waves per workgroup
 constexpr int IPT = 16;          // rounds per wave
 constexpr int TILE = NT * IPT;   // entries per tile (8192)
 constexpr int WCHUNK = 64 * IPT; // entries per wave (1024)
+#ifndef RLE_IPT_NARROW
+#define RLE_IPT_NARROW 24
+#endif
+#ifndef RLE_IPT_WIDE
+#define RLE_IPT_WIDE 16
+#endif
 constexpr int RADIX = 256;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int FILL_INLINE = 32;          // row-pointer gaps up to this many rows are filled by the finding lane
@@ -957,12 +963,15 @@ __device__ __forceinline__ u64 lookback_exclusive(u64 *status, uint32_t tile, u6
 //   scal[0] = E (instances, input), scal[1] = nnz (output), scal[2] = ntasks, scal[3] = err, scal[5] = ticket
 // Narrow entries are widened to the 8-byte form (k-mer id << 32 | column) as they are loaded (the id's upper part is
 // the region the entry sits in), so everything after the loads is common to both forms.
-template <class ET>
+// RIPT rounds per wave: a tile of this kernel is NT * RIPT entries (larger than the partition's: every tile pays one
+// chained-scan hand-off, ~5 us of mostly idle workgroup, so fewer and larger tiles win).
+template <class ET, int RIPT>
 __global__ __launch_bounds__(NT, 4) void k_rle(const ET *ent, uint32_t *scal, u64 *status, const uint32_t *rec_total,
                                                uint64_t first_col, uint64_t M, uint64_t max_nz, float *data, uint64_t *col_ind,
                                                uint64_t *row_ind, FillTask *tasks, uint32_t task_cap, const uint32_t *regions,
                                                int key_shift) {
     constexpr bool NARROW = sizeof(ET) == 4;
+    constexpr int R_TILE = NT * RIPT, R_WCHUNK = 64 * RIPT;
     __shared__ uint32_t sreg[NARROW ? RADIX + 1 : 1];
     __shared__ uint32_t s_tile;
     __shared__ uint32_t s_cnt[NW], s_first[NW];
@@ -976,67 +985,73 @@ __global__ __launch_bounds__(NT, 4) void k_rle(const ET *ent, uint32_t *scal, u6
         for (uint32_t i = tid; i <= RADIX; i += NT) sreg[i] = regions[i];
     lds_sync();
     const uint32_t tile = s_tile;
-    // entry i in the 8-byte form; `r` = its region if already known, NONE to search for it
-    auto wide_at = [&](uint64_t i, uint32_t r) -> u64 {
-        if constexpr (NARROW) {
-            const uint32_t v = ent[i];
-            if (r == NONE) r = region_search(sreg, (uint32_t)i);
-            const uint32_t key = key_shift ? ((r << 8) | (v >> 24)) : r;
-            return make_entry(key, v & 0xFFFFFFu);
-        } else {
-            return ent[i];
-        }
-    };
     if (E == 0) {  // no instance at all: every row pointer is 0
         if (tile == 0 && tid == 0) fill_rows(row_ind, 0, M + 1, 0, tasks, p_ntasks, task_cap, p_err);
         return;
     }
-    const uint64_t base = (uint64_t)tile * TILE;
+    const uint64_t base = (uint64_t)tile * R_TILE;
     if (base >= E) return;
-    const uint32_t wbase_i = (uint32_t)base + w * WCHUNK;
+    const uint32_t wbase_i = (uint32_t)base + w * R_WCHUNK;
+    const uint64_t tile_end = base + R_TILE;
 
-    // ---- load, head flags
-    u64 e[IPT];
-    if constexpr (NARROW) {
-        uint32_t v[IPT];  // all loads in flight before any region work
-#pragma unroll
-        for (int j = 0; j < IPT; ++j) {
-            const uint64_t i = (uint64_t)wbase_i + j * 64 + lane;
-            v[j] = (i < E) ? ent[i] : 0u;
+    // Narrow entries are compared as they are stored (byte << 24 | column): inside a region that is the order and the
+    // equality of the 8-byte form; where a region starts, the entry is a head (and a row head) whatever its value.
+    // The k-mer id (region << 8 | byte, or the region alone) is rebuilt only where a row starts.
+    auto key_of = [&](uint32_t i, ET v) -> uint32_t {
+        if constexpr (NARROW) {
+            const uint32_t r = region_search(sreg, i);
+            return key_shift ? ((r << 8) | ((uint32_t)v >> 24)) : r;
+        } else {
+            return entry_key((u64)v);
         }
-        const uint32_t r0 = region_search(sreg, wbase_i < E ? wbase_i : E - 1);  // wave-uniform lower bound
-        const bool one_region = sreg[r0 + 1] >= wbase_i + WCHUNK || sreg[r0 + 1] >= E;  // nearly always: 256 regions
-        uint32_t r = r0;
+    };
+    auto col_of = [&](ET v) -> uint32_t {
+        if constexpr (NARROW)
+            return (uint32_t)v & 0xFFFFFFu;
+        else
+            return entry_col((u64)v);
+    };
+    auto same_row = [&](ET a, ET b) -> bool {  // for entries of one region
+        if constexpr (NARROW)
+            return key_shift ? (((uint32_t)a >> 24) == ((uint32_t)b >> 24)) : true;
+        else
+            return entry_key((u64)a) == entry_key((u64)b);
+    };
+
+    // ---- loads: the wave's 16 rounds, the entry before its chunk, and (last wave) the probe behind the tile
+    ET e[RIPT];
 #pragma unroll
-        for (int j = 0; j < IPT; ++j) {
-            const uint32_t i = wbase_i + j * 64 + lane;
-            if (i < E) {
-                if (!one_region) r = region_from(sreg, i, r);
-                const uint32_t key = key_shift ? ((r << 8) | (v[j] >> 24)) : r;
-                e[j] = make_entry(key, v[j] & 0xFFFFFFu);
-            } else {
-                e[j] = ~0ull;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < IPT; ++j) {
-            const uint64_t i = (uint64_t)wbase_i + j * 64 + lane;
-            e[j] = (i < E) ? ent[i] : ~0ull;
-        }
+    for (int j = 0; j < RIPT; ++j) {
+        const uint64_t i = (uint64_t)wbase_i + j * 64 + lane;
+        e[j] = (i < E) ? ent[i] : (ET)0;
     }
-    const u64 carry0 = (wbase_i > 0 && lane == 0) ? wide_at(wbase_i - 1, NONE) : 0ull;  // the entry before this wave's chunk
-    u64 carry = carry0;
-    u64 hm[IPT], rm[IPT];  // head lanes / heads that also start a new row (wave-uniform masks)
+    const ET carry0 = (wbase_i > 0 && lane == 0) ? ent[wbase_i - 1] : (ET)0;
+    ET probe = 0;
+    if (w == NW - 1 && tile_end + lane < E) probe = ent[tile_end + lane];
+
+    // does a region start inside this wave's chunk (or exactly at its first entry)?  Nearly never: 256 regions.
+    bool has_b = false;
+    if constexpr (NARROW) {
+        const uint32_t r0 = region_search(sreg, wbase_i < E ? wbase_i : E - 1);
+        const uint32_t nb = sreg[r0 + 1];
+        has_b = (sreg[r0] == wbase_i) || (nb < wbase_i + R_WCHUNK && nb < E);
+    }
+
+    ET carry = carry0;
+    u64 hm[RIPT], rm[RIPT];  // head lanes / heads that also start a new row (wave-uniform masks)
     uint32_t cnt = 0;
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) {
+    for (int j = 0; j < RIPT; ++j) {
         const uint32_t i = wbase_i + j * 64 + lane;
-        u64 prev = __shfl_up(e[j], 1);
+        ET prev = __shfl_up(e[j], 1);
         if (lane == 0) prev = carry;
         const bool in = i < E;
-        const bool head = in && (i == 0 || e[j] != prev);
-        const bool rowh = head && (i == 0 || entry_key(e[j]) != entry_key(prev));
+        bool rs = false;  // a region starts at i
+        if constexpr (NARROW) {
+            if (has_b) rs = in && sreg[region_search(sreg, in ? i : 0u)] == i;
+        }
+        const bool head = in && (i == 0 || rs || e[j] != prev);
+        const bool rowh = head && (i == 0 || rs || !same_row(e[j], prev));
         hm[j] = __ballot(head);
         rm[j] = __ballot(rowh);
         cnt += (uint32_t)__popcll(hm[j]);
@@ -1044,31 +1059,32 @@ __global__ __launch_bounds__(NT, 4) void k_rle(const ET *ent, uint32_t *scal, u6
     }
     uint32_t first = NONE;
 #pragma unroll
-    for (int j = IPT - 1; j >= 0; --j)
+    for (int j = RIPT - 1; j >= 0; --j)
         if (hm[j]) first = wbase_i + j * 64 + (uint32_t)__ffsll((long long)hm[j]) - 1u;
     if (lane == 0) {
         s_cnt[w] = cnt;
         s_first[w] = first;
     }
     // ---- the last run of the tile may go on in the following tiles: find the next head after the tile.
-    // The array is sorted as 64-bit values (k-mer id major, column minor), so that head is the first entry greater
-    // than the tile's last one: one 64-entry probe (the common case), then a binary search -- O(log E) even when one
-    // run spans the rest of the array (a single poly-A record of any length).
+    // The array is sorted (k-mer id major, column minor; narrow: by value inside a region), so that head is the first
+    // entry greater than the tile's last one: the 64-entry probe loaded above (the common case), then a binary search
+    // -- O(log E) even when one run spans the rest of the array (a single poly-A record of any length).
     if (w == NW - 1) {
-        const uint64_t tile_end = base + TILE;
         uint32_t nxt = E;
         if (tile_end < E) {
-            const u64 last = wide_at(tile_end - 1, NONE);
+            const ET last = __shfl(e[RIPT - 1], 63);  // entry tile_end - 1 (the tile is full)
+            uint64_t limit = E;                       // first index at or after tile_end where a region starts
+            if constexpr (NARROW) limit = sreg[region_search(sreg, (uint32_t)tile_end - 1u) + 1];
             const uint64_t i = tile_end + lane;
-            const u64 dm = __ballot((i < E) ? (wide_at(i, NONE) != last) : true);
+            const u64 dm = __ballot((i < limit) ? (probe != last) : true);
             if (dm) {
                 const uint64_t at = tile_end + (uint32_t)__ffsll((long long)dm) - 1u;
                 nxt = (at < E) ? (uint32_t)at : E;
             } else {
-                uint64_t lo = tile_end + 64, hi = E;  // first index in [lo, hi] whose entry is > last
+                uint64_t lo = tile_end + 64, hi = limit;  // first index in [lo, hi] whose entry is > last (hi if none)
                 while (lo < hi) {
                     const uint64_t mid = (lo + hi) >> 1;
-                    if (wide_at(mid, NONE) > last)
+                    if (ent[mid] > last)
                         hi = mid;
                     else
                         lo = mid + 1;
@@ -1088,7 +1104,11 @@ __global__ __launch_bounds__(NT, 4) void k_rle(const ET *ent, uint32_t *scal, u6
     }
     // ---- heads before this tile (chained scan), by wave 0
     if (w == 0) {
+#ifdef KK_RLE_NOLOOKBACK
+        const u64 ex = base;
+#else
         const u64 ex = lookback_exclusive(status, tile, n_heads, p_err);
+#endif
         if (lane == 0) s_out0 = ex;
     }
     lds_sync();
@@ -1100,41 +1120,56 @@ __global__ __launch_bounds__(NT, 4) void k_rle(const ET *ent, uint32_t *scal, u6
         if ((uint32_t)i > w && s_first[i] != NONE) after = s_first[i];
 
     // ---- emit.  nxt_after = first head in rounds > j (wave-uniform), walked backwards
-    uint32_t nxt_after[IPT];
+    uint32_t nxt_after[RIPT];
     {
         uint32_t nh = after;
 #pragma unroll
-        for (int j = IPT - 1; j >= 0; --j) {
+        for (int j = RIPT - 1; j >= 0; --j) {
             nxt_after[j] = nh;
             if (hm[j]) nh = wbase_i + j * 64 + (uint32_t)__ffsll((long long)hm[j]) - 1u;
         }
     }
     uint32_t run = wave_before;
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) {
+    for (int j = 0; j < RIPT; ++j) {
         if (hm[j] == 0) continue;  // wave-uniform
         const uint32_t i = wbase_i + j * 64 + lane;
-        u64 prev = __shfl_up(e[j], 1);
-        const u64 prev0 = (j > 0) ? __shfl(e[j > 0 ? j - 1 : 0], 63) : carry0;
+        ET prev = __shfl_up(e[j], 1);
+        const ET prev0 = (j > 0) ? __shfl(e[j > 0 ? j - 1 : 0], 63) : carry0;
         if (lane == 0) prev = prev0;
         if ((hm[j] >> lane) & 1ull) {
             const u64 above = (lane == 63) ? 0ull : (hm[j] >> (lane + 1));
             const uint32_t nxt = above ? i + (uint32_t)__ffsll((long long)above) : nxt_after[j];
             const u64 o = out0 + run + (uint32_t)__popcll(hm[j] & lanes_below(lane));
-            const uint32_t k = entry_key(e[j]), c = entry_col(e[j]);
+            const uint32_t c = col_of(e[j]);
             if (o < max_nz) {
                 // reference: float(count) / total_count with total_count uint32_t: both operands are rounded to
                 // float, then one IEEE float division (hipcc's default float division is correctly rounded)
-                data[o] = (float)(nxt - i) / (float)rec_total[c];
+#ifdef KK_RLE_NOGATHER  // diagnostic builds (wrong results): what the rec_total gather costs
+                const uint32_t total = c | 1u;
+#else
+                const uint32_t total = rec_total[c];
+#endif
+#ifdef KK_RLE_NOSTORE
+                if (total == 0x7FFFFFFFu)
+#endif
+                data[o] = (float)(nxt - i) / (float)total;
+#ifdef KK_RLE_NOSTORE
+                if (total == 0x7FFFFFFFu)
+#endif
                 col_ind[o] = first_col + c;
             }
-            if ((rm[j] >> lane) & 1ull) {
-                const uint64_t lo = (i == 0) ? 0ull : (uint64_t)entry_key(prev) + 1;
-                fill_rows(row_ind, lo, (uint64_t)k + 1, o, tasks, p_ntasks, task_cap, p_err);
-            }
-            if (nxt == E) {  // the last head of all
-                *p_nnz = (uint32_t)(o + 1);
-                fill_rows(row_ind, (uint64_t)k + 1, M + 1, o + 1, tasks, p_ntasks, task_cap, p_err);
+            const bool row_head = (rm[j] >> lane) & 1ull, last_head = nxt == E;
+            if (row_head || last_head) {  // rare: at most M + 1 lanes of the whole launch
+                const uint32_t k = key_of(i, e[j]);
+                if (row_head) {
+                    const uint64_t lo = (i == 0) ? 0ull : (uint64_t)key_of(i - 1, prev) + 1;
+                    fill_rows(row_ind, lo, (uint64_t)k + 1, o, tasks, p_ntasks, task_cap, p_err);
+                }
+                if (last_head) {  // the last head of all
+                    *p_nnz = (uint32_t)(o + 1);
+                    fill_rows(row_ind, (uint64_t)k + 1, M + 1, o + 1, tasks, p_ntasks, task_cap, p_err);
+                }
             }
         }
         run += (uint32_t)__popcll(hm[j]);
@@ -1538,7 +1573,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
             ei = eo, eo = t;
             final_regions = regs1;
         }
-        hipLaunchKernelGGL(k_rle<uint32_t>, grid, block, 0, s, (const uint32_t *)ei, scal, status, (const uint32_t *)total, first_col, M,
+        hipLaunchKernelGGL((k_rle<uint32_t, RLE_IPT_NARROW>), dim3((uint32_t)(((uint64_t)l.n_tiles * TILE + NT * RLE_IPT_NARROW - 1) / (NT * RLE_IPT_NARROW))), block, 0, s, (const uint32_t *)ei, scal, status, (const uint32_t *)total, first_col, M,
                            max_nz, d_data, d_col_ind, d_row_ind, tasks, l.task_cap, final_regions, n_pass > 1 ? 8 : 0);
     } else {
         u64 *ei = entA, *eo = entB;
@@ -1557,7 +1592,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
             u64 *t = ei;
             ei = eo, eo = t;
         }
-        hipLaunchKernelGGL(k_rle<u64>, grid, block, 0, s, (const u64 *)ei, scal, status, (const uint32_t *)total, first_col, M, max_nz,
+        hipLaunchKernelGGL((k_rle<u64, RLE_IPT_WIDE>), dim3((uint32_t)(((uint64_t)l.n_tiles * TILE + NT * RLE_IPT_WIDE - 1) / (NT * RLE_IPT_WIDE))), block, 0, s, (const u64 *)ei, scal, status, (const uint32_t *)total, first_col, M, max_nz,
                            d_data, d_col_ind, d_row_ind, tasks, l.task_cap, (const uint32_t *)nullptr, 0);
     }
     pt.mark("k_rle");
