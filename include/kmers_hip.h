@@ -134,6 +134,17 @@ int kmers_hip_debug_stamps(unsigned long long *out16, int reset);
 int kmers_csr_merge(int n_parts, uint64_t n_rows, const float *const data[], const uint64_t *const row_ind[],
                     const uint64_t *const col_ind[], float *out_data, uint64_t *out_row_ind, uint64_t *out_col_ind);
 
+/* ---- X as the reference's .npz --------------------------------------------- */
+
+/* Write the CSR arrays of the ABI as the uncompressed scipy .npz that the reference's transcriptome_to_x saves
+ * (kmerexpr/transcriptome_reader.py:39, scipy.sparse.save_npz(x_file, xt, compressed=False)): members indices, indptr
+ * (int32 when n_rows, n_cols and nnz all fit, else int64 -- scipy's rule), format, shape, data; stored ZIP with
+ * ZIP64 records.  The uint64 indices are narrowed chunk by chunk on the way out and the CRCs computed on all host
+ * threads, so no second copy of X is made.  Host memory in, file out.  Returns 0, KMERS_ERR_OPEN (cannot create or
+ * write the file) or KMERS_ERR_BAD_ARG. */
+int kmers_npz_write_csr(const char *path, const float *data, const uint64_t *col_ind, const uint64_t *row_ind,
+                        uint64_t nnz, uint64_t n_rows, uint64_t n_cols);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,8 @@ def handle():
                                       vp, vp, vp, C.c_uint64, vp, C.c_size_t, C.POINTER(C.c_uint64), vp]
     lib.kmers_csr_merge.restype = C.c_int
     lib.kmers_csr_merge.argtypes = [C.c_int, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp, vp]
+    lib.kmers_npz_write_csr.restype = C.c_int
+    lib.kmers_npz_write_csr.argtypes = [C.c_char_p, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64]
     lib.kmers_hip_profile_enable.restype, lib.kmers_hip_profile_enable.argtypes = None, [C.c_int]
     lib.kmers_hip_profile_count.restype, lib.kmers_hip_profile_count.argtypes = C.c_int, []
     lib.kmers_hip_profile_get.restype = C.c_int

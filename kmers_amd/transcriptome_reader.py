@@ -1,9 +1,28 @@
 """`transcriptome_to_x` / `load_xy` with the reference's signatures and .npz output
 (reference kmerexpr/transcriptome_reader.py:6-41), on the HIP build of libkmers."""
 import numpy as np
-from scipy.sparse import csr_matrix, load_npz, save_npz
+from scipy.sparse import csr_matrix, load_npz
 
+from . import _lib
 from .libkmers import fasta_to_kmers_csr
+
+
+def save_x_npz(x_file, data, row_ind, col_ind, n_rows, n_cols):
+    """The file scipy.sparse.save_npz(x_file, csr_matrix((data, col_ind, row_ind)), compressed=False) would hold
+    (same members, dtypes and values; reference kmerexpr/transcriptome_reader.py:39), written by the library
+    straight from the ABI's uint64 / float32 arrays (kmers_npz_write_csr)."""
+    x_file = str(x_file)
+    if not x_file.endswith(".npz"):
+        x_file += ".npz"           # what scipy's save_npz does
+    data = np.ascontiguousarray(data, dtype=np.float32)
+    row_ind = np.ascontiguousarray(row_ind, dtype=np.uint64)
+    col_ind = np.ascontiguousarray(col_ind, dtype=np.uint64)
+    assert row_ind.shape[0] == n_rows + 1 and col_ind.shape[0] == data.shape[0]
+    rc = _lib.handle().kmers_npz_write_csr(x_file.encode("UTF-8"), data.ctypes.data, col_ind.ctypes.data,
+                                           row_ind.ctypes.data, data.shape[0], n_rows, n_cols)
+    if rc == -1:
+        raise OSError(f"cannot write {x_file}")
+    _lib.check(rc, "kmers_npz_write_csr")
 
 
 def load_xy(x_file, y_file):
@@ -22,7 +41,6 @@ def transcriptome_to_x(K, fasta_files, x_file="", L=0, max_nz=0, float_t=np.floa
     M = 4 ** K
     data, row_ind, col_ind, n_cols = fasta_to_kmers_csr(fasta_files, K, max_nz, L=L,
                                                         concatenate_subseq=concatenate_subseq)
-    xt = csr_matrix((data, col_ind, row_ind), shape=(M, n_cols), dtype=float_t)
     if x_file:
-        save_npz(x_file, xt, compressed=False)
-    return xt
+        save_x_npz(x_file, data, row_ind, col_ind, M, n_cols)
+    return csr_matrix((data, col_ind, row_ind), shape=(M, n_cols), dtype=float_t)
