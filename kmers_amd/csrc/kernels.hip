@@ -116,10 +116,10 @@ __device__ __forceinline__ uint32_t region_from(const uint32_t *sreg, uint32_t i
     while (sreg[r + 1] <= i) ++r;
     return r;
 }
-// regions[d] = tilebase[d][tile 0] of a scanned digit-major tile histogram; regions[256] = entry count
+// regions[d] = tilebase[tile 0][d] of the scanned tile histogram; regions[256] = entry count
 __global__ void k_regions(const uint32_t *tilebase, uint32_t n_tiles, const uint32_t *p_count, uint32_t *regions) {
     const uint32_t d = threadIdx.x;
-    if (d < RADIX) regions[d] = tilebase[(uint64_t)d * n_tiles];
+    if (d < RADIX) regions[d] = tilebase[d];
     if (d == RADIX) regions[RADIX] = *p_count;
 }
 
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(NT) void k_hist_bases(BasesArgs a, uint32_t *tilehi
             uint32_t s = 0;
 #pragma unroll
             for (int i = 0; i < NW; ++i) s += h[i][tid];
-            tilehist[(uint64_t)tid * n_tiles + tile] = s;
+            tilehist[(uint64_t)tile * RADIX + tid] = s;
         }
         lds_sync();
     }
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(NT) void k_hist_entries(const ET *ent, const uint32
         uint32_t s = 0;
 #pragma unroll
         for (int i = 0; i < NW; ++i) s += h[i][tid];
-        tilehist[(uint64_t)tid * n_tiles + tile] = s;
+        tilehist[(uint64_t)tile * RADIX + tid] = s;
     }
 }
 
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
             }
         }
     }
-    uint32_t gb = (tid < RADIX) ? tilebase[(uint64_t)tid * n_tiles + t0] : 0u;
+    uint32_t gb = (tid < RADIX) ? tilebase[(uint64_t)t0 * RADIX + tid] : 0u;
 
     KK_STAMP_BEGIN();
     for (uint32_t tile = t0; tile < t1; ++tile) {
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
 #pragma unroll
             for (int i = 0; i < NW; ++i) wcnt[i][tid] = dstart + wc[i];
             gadj[tid] = gb - dstart;
-            if (tile + 1 < t1) gb = tilebase[(uint64_t)tid * n_tiles + tile + 1];
+            if (tile + 1 < t1) gb = tilebase[(uint64_t)(tile + 1) * RADIX + tid];
         }
         lds_sync();
         KK_STAMP(3);  // digit scan
@@ -829,55 +829,83 @@ __global__ __launch_bounds__(YS_NT) void k_count_y_overflow(const uint32_t *ent,
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Exclusive scan of a uint32 array (three launches; the array is the digit-major tile histogram)
+// Scan of the tile histogram
 // ------------------------------------------------------------------------------------------------------
+//
+// hist[tile][digit] (tile-major: a tile's 256 counts are one 1 KB row, written and read coalesced) becomes, in place,
+// base[tile][digit] = position of the first entry of (digit, tile) in the partitioned array
+//                   = (entries of smaller digits, all tiles) + (entries of this digit in earlier tiles),
+// i.e. the exclusive scan in digit-major order, computed as 256 column scans plus a 256-value scan of the totals.
+// Three launches: sums per chunk of CSCAN_TILES tiles; one workgroup turns them into chunk bases; apply.
 
-constexpr int SCAN_IPT = 8;
-constexpr int SCAN_CHUNK = NT * SCAN_IPT;  // 4096 values per workgroup
+constexpr int CSCAN_TILES = 64, CSCAN_SEG = 4;
 
-__global__ __launch_bounds__(NT) void k_scan_reduce(const uint32_t *in, uint64_t n, uint32_t *block_sums) {
-    __shared__ uint32_t stmp[NW];
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_IPT;
+__global__ __launch_bounds__(RADIX) void k_cscan_reduce(const uint32_t *hist, uint32_t n_tiles, uint32_t *chunk_sums) {
+    const uint32_t d = threadIdx.x, c = blockIdx.x;
+    const uint32_t t0 = c * CSCAN_TILES, t1 = (t0 + CSCAN_TILES < n_tiles) ? t0 + CSCAN_TILES : n_tiles;
     uint32_t s = 0;
-#pragma unroll
-    for (int j = 0; j < SCAN_IPT; ++j)
-        if (base + j < n) s += in[base + j];
-    uint32_t tot;
-    (void)block_excl_scan(s, stmp, tot);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+#pragma unroll 8
+    for (uint32_t t = t0; t < t1; ++t) s += hist[(uint64_t)t * RADIX + d];
+    chunk_sums[(uint64_t)c * RADIX + d] = s;
 }
 
-// One workgroup: exclusive scan of block_sums in place; grand total to *p_total.
-__global__ __launch_bounds__(NT) void k_scan_block_sums(uint32_t *block_sums, uint32_t n_blocks, uint32_t *p_total) {
-    __shared__ uint32_t stmp[NW];
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < n_blocks; base += NT) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = (i < n_blocks) ? block_sums[i] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan(v, stmp, tot);
-        if (i < n_blocks) block_sums[i] = carry + ex;
-        carry += tot;
+// One workgroup of RADIX * CSCAN_SEG threads: thread (seg, d) owns a quarter of digit d's chunks.
+__global__ __launch_bounds__(RADIX *CSCAN_SEG) void k_cscan_mid(uint32_t *chunk_sums, uint32_t n_chunks, uint32_t *p_total) {
+    __shared__ uint32_t seg_sum[CSCAN_SEG][RADIX];
+    __shared__ uint32_t dbase[RADIX];
+    __shared__ uint32_t stmp[RADIX * CSCAN_SEG / 64];
+    const uint32_t d = threadIdx.x % RADIX, seg = threadIdx.x / RADIX;
+    const uint32_t per = (n_chunks + CSCAN_SEG - 1) / CSCAN_SEG;
+    const uint32_t c0 = seg * per < n_chunks ? seg * per : n_chunks, c1 = (c0 + per < n_chunks) ? c0 + per : n_chunks;
+    uint32_t s = 0;
+#pragma unroll 8
+    for (uint32_t c = c0; c < c1; ++c) s += chunk_sums[(uint64_t)c * RADIX + d];
+    seg_sum[seg][d] = s;
+    __syncthreads();
+    // digit totals -> exclusive scan over the digits (threads of segment 0 carry the values, the others zero)
+    uint32_t total = 0;
+    if (seg == 0)
+        for (int i = 0; i < CSCAN_SEG; ++i) total += seg_sum[i][d];
+    // block_excl_scan is written for NT threads; this workgroup has RADIX * CSCAN_SEG: scan by hand
+    {
+        const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
+        uint32_t incl = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            if (lane >= (uint32_t)o) incl += t;
+        }
+        if (lane == 63) stmp[w] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, all = 0;
+        for (uint32_t i = 0; i < RADIX * CSCAN_SEG / 64; ++i) {
+            const uint32_t t = stmp[i];
+            if (i < w) wbase += t;
+            all += t;
+        }
+        if (seg == 0) dbase[d] = wbase + incl - total;
+        if (threadIdx.x == 0) *p_total = all;
     }
-    if (threadIdx.x == 0) *p_total = carry;
+    __syncthreads();
+    uint32_t run = dbase[d];
+    for (uint32_t i = 0; i < seg; ++i) run += seg_sum[i][d];
+#pragma unroll 8
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint32_t v = chunk_sums[(uint64_t)c * RADIX + d];
+        chunk_sums[(uint64_t)c * RADIX + d] = run;
+        run += v;
+    }
 }
 
-__global__ __launch_bounds__(NT) void k_scan_apply(const uint32_t *in, uint64_t n, const uint32_t *block_sums, uint32_t *out) {
-    __shared__ uint32_t stmp[NW];
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_IPT;
-    uint32_t v[SCAN_IPT];
-    uint32_t s = 0;
-#pragma unroll
-    for (int j = 0; j < SCAN_IPT; ++j) {
-        v[j] = (base + j < n) ? in[base + j] : 0u;
-        s += v[j];
-    }
-    uint32_t tot;
-    uint32_t run = block_sums[blockIdx.x] + block_excl_scan(s, stmp, tot);
-#pragma unroll
-    for (int j = 0; j < SCAN_IPT; ++j) {
-        if (base + j < n) out[base + j] = run;
-        run += v[j];
+__global__ __launch_bounds__(RADIX) void k_cscan_apply(uint32_t *hist, uint32_t n_tiles, const uint32_t *chunk_base) {
+    const uint32_t d = threadIdx.x, c = blockIdx.x;
+    const uint32_t t0 = c * CSCAN_TILES, t1 = (t0 + CSCAN_TILES < n_tiles) ? t0 + CSCAN_TILES : n_tiles;
+    uint32_t run = chunk_base[(uint64_t)c * RADIX + d];
+#pragma unroll 8
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t v = hist[(uint64_t)t * RADIX + d];
+        hist[(uint64_t)t * RADIX + d] = run;
+        run += v;
     }
 }
 
@@ -1265,6 +1293,7 @@ int read_stamps(unsigned long long *out16, bool reset) {
 int read_stamps(unsigned long long *, bool) { return -12; }
 #endif
 
+static inline uint32_t cscan_chunks(uint32_t n_tiles) { return (n_tiles + CSCAN_TILES - 1) / CSCAN_TILES; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct XLayout {
@@ -1281,7 +1310,7 @@ static XLayout x_layout(uint64_t n_pos, uint64_t n_rec, int K) {
     const uint64_t emax = n_pos ? n_pos : 1;
     l.n_tiles = (uint32_t)((emax + TILE - 1) / TILE);
     l.hist_len = (uint64_t)RADIX * l.n_tiles;
-    l.scan_blocks = (uint32_t)((l.hist_len + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    l.scan_blocks = cscan_chunks(l.n_tiles);
     const uint64_t M = 1ull << (2 * K);
     // long gaps: each holds > FILL_INLINE rows and follows a row head, plus the splits of very long ones
     uint64_t cap = (M + 1) / (FILL_INLINE + 1) + 2;
@@ -1297,7 +1326,7 @@ static XLayout x_layout(uint64_t n_pos, uint64_t n_rec, int K) {
     l.off_entA = take(emax * 8);
     l.off_entB = take(emax * 8);
     l.off_hist = take(l.hist_len * 4);
-    l.off_blocksums = take((size_t)l.scan_blocks * 4 + 4);
+    l.off_blocksums = take((size_t)l.scan_blocks * RADIX * 4);
     l.off_total = take((n_rec ? n_rec : 1) * 4);
     l.off_flags = take(((emax + 31) / 32 + 4) * 4);
     l.off_tilecb = take(((size_t)l.n_tiles + 2) * 4);
@@ -1320,11 +1349,12 @@ size_t x_workspace_bytes(uint64_t n_pos, uint64_t n_rec, int K) { return x_layou
         }                                                                                                \
     } while (0)
 
-static int scan_u32(const uint32_t *in, uint64_t n, uint32_t *out, uint32_t *block_sums, uint32_t n_blocks, uint32_t *p_total,
-                    hipStream_t s) {
-    hipLaunchKernelGGL(k_scan_reduce, dim3(n_blocks), dim3(NT), 0, s, in, n, block_sums);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(NT), 0, s, block_sums, n_blocks, p_total);
-    hipLaunchKernelGGL(k_scan_apply, dim3(n_blocks), dim3(NT), 0, s, in, n, block_sums, out);
+// hist[n_tiles][RADIX] -> bases in place; *p_total = number of entries.  chunk_sums: cscan_chunks(n_tiles) * RADIX words.
+static int scan_tilehist(uint32_t *hist, uint32_t n_tiles, uint32_t *chunk_sums, uint32_t *p_total, hipStream_t s) {
+    const uint32_t nc = cscan_chunks(n_tiles);
+    hipLaunchKernelGGL(k_cscan_reduce, dim3(nc), dim3(RADIX), 0, s, (const uint32_t *)hist, n_tiles, chunk_sums);
+    hipLaunchKernelGGL(k_cscan_mid, dim3(1), dim3(RADIX * CSCAN_SEG), 0, s, chunk_sums, nc, p_total);
+    hipLaunchKernelGGL(k_cscan_apply, dim3(nc), dim3(RADIX), 0, s, hist, n_tiles, (const uint32_t *)chunk_sums);
     KK_CHECK(hipGetLastError());
     return 0;
 }
@@ -1346,7 +1376,7 @@ static YLayout y_layout_for(uint32_t chunk_tiles, int K) {
     YLayout l;
     l.chunk_tiles = chunk_tiles;
     l.hist_len = (uint64_t)RADIX * chunk_tiles;
-    l.scan_blocks = (uint32_t)((l.hist_len + SCAN_CHUNK - 1) / SCAN_CHUNK);
+    l.scan_blocks = cscan_chunks(chunk_tiles);
     l.n_buf = (K >= 13) ? 2 : 1;
     const int low_bits = 2 * K - (K >= 13 ? 16 : 8);  // 10..16
     // one pass: a slice is at most one region (low_bits 10, 12, 14 -> the whole region, 16 -> half of it);
@@ -1363,7 +1393,7 @@ static YLayout y_layout_for(uint32_t chunk_tiles, int K) {
     l.off_entA = take(ent);
     l.off_entB = take(l.n_buf == 2 ? ent : 0);
     l.off_hist = take(l.hist_len * 4);
-    l.off_blocksums = take((size_t)l.scan_blocks * 4 + 4);
+    l.off_blocksums = take((size_t)l.scan_blocks * RADIX * 4);
     l.off_scalars = take(64);
     l.off_regions = take(2 * (RADIX + 1) * 4);
     l.off_ovf = take((size_t)l.slices * sizeof(YOverflow));
@@ -1453,8 +1483,6 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     const uint64_t n_ranges = two_pass ? (slices < 65536u ? slices : 65536u) : 256u;
     for (uint64_t t0 = 0; t0 < n_tiles; t0 += chunk_tiles) {
         const uint32_t nt = (uint32_t)((n_tiles - t0 < chunk_tiles) ? n_tiles - t0 : chunk_tiles);
-        const uint64_t hist_len = (uint64_t)RADIX * nt;
-        const uint32_t scan_blocks = (uint32_t)((hist_len + SCAN_CHUNK - 1) / SCAN_CHUNK);
         a.tile0 = t0;
         a.low_bits = low_bits;
         KK_CHECK(hipMemsetAsync(scal, 0, 64, s));  // [8] = length of the overflow queue
@@ -1469,7 +1497,7 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         const uint32_t *c_hist = hist, *c_E = &scal[0];
         hipLaunchKernelGGL(k_hist_bases<true>, hgrid, block, 0, s, a, hist, nt, (uint32_t *)nullptr);
         pt.mark("k_hist_bases<y>");
-        if (int rc = scan_u32(hist, hist_len, hist, bsum, scan_blocks, &scal[0], s)) return rc;
+        if (int rc = scan_tilehist(hist, nt, bsum, &scal[0], s)) return rc;
         pt.mark("k_scan");
         hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, nt, c_E, regs0);
         hipLaunchKernelGGL((k_scatter<true, uint32_t, true>), pgrid, block, 0, s, a, (const uint32_t *)nullptr, c_E, 0, c_hist, nt, entA,
@@ -1479,7 +1507,7 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         if (two_pass) {
             hipLaunchKernelGGL(k_hist_entries<uint32_t>, grid, block, 0, s, (const uint32_t *)entA, c_E, 8, hist, nt);
             pt.mark("k_hist_entries");
-            if (int rc = scan_u32(hist, hist_len, hist, bsum, scan_blocks, &scal[4], s)) return rc;
+            if (int rc = scan_tilehist(hist, nt, bsum, &scal[4], s)) return rc;
             pt.mark("k_scan");
             hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, nt, c_E, regs1);
             hipLaunchKernelGGL((k_scatter<false, uint32_t>), pgrid, block, 0, s, a, (const uint32_t *)entA, c_E, 8, c_hist, nt, entB,
@@ -1551,7 +1579,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     // pass 0: packed bases -> instances partitioned by the lowest digit
     hipLaunchKernelGGL(k_hist_bases<false>, hgrid, block, 0, s, a, hist, l.n_tiles, total);
     pt.mark("k_hist_bases");
-    if (int rc = scan_u32(hist, l.hist_len, hist, bsum, l.scan_blocks, &scal[0], s)) return rc;
+    if (int rc = scan_tilehist(hist, l.n_tiles, bsum, &scal[0], s)) return rc;
     pt.mark("k_scan");
     const uint32_t *final_regions = regs0;
     if (narrow) {
@@ -1563,7 +1591,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         if (n_pass > 1) {
             hipLaunchKernelGGL(k_hist_entries<uint32_t>, grid, block, 0, s, (const uint32_t *)ei, c_E, 8, hist, l.n_tiles);
             pt.mark("k_hist_entries");
-            if (int rc = scan_u32(hist, l.hist_len, hist, bsum, l.scan_blocks, &scal[4], s)) return rc;
+            if (int rc = scan_tilehist(hist, l.n_tiles, bsum, &scal[4], s)) return rc;
             pt.mark("k_scan");
             hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, l.n_tiles, c_E, regs1);
             hipLaunchKernelGGL((k_scatter<false, uint32_t>), pgrid, block, 0, s, a, (const uint32_t *)ei, c_E, 8, c_hist, l.n_tiles, eo,
@@ -1584,7 +1612,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
             const int shift = 8 * p;
             hipLaunchKernelGGL(k_hist_entries<u64>, grid, block, 0, s, (const u64 *)ei, c_E, shift, hist, l.n_tiles);
             pt.mark("k_hist_entries");
-            if (int rc = scan_u32(hist, l.hist_len, hist, bsum, l.scan_blocks, &scal[4], s)) return rc;
+            if (int rc = scan_tilehist(hist, l.n_tiles, bsum, &scal[4], s)) return rc;
             pt.mark("k_scan");
             hipLaunchKernelGGL((k_scatter<false, u64>), pgrid, block, 0, s, a, (const u64 *)ei, c_E, shift, c_hist, l.n_tiles, eo,
                                (const uint32_t *)nullptr);

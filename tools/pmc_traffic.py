@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""HBM traffic per kernel launch from the FETCH_SIZE / WRITE_SIZE passes of tools/pmc.sh, corrected as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts 128-byte requests as 64: doubled;
+both counters are in KiB).  Writes kmers_amd/data/pmc_traffic.json, which bench.py quotes as roofline.traffic.
+
+    tools/pmc_traffic.py gpurun_out/pmc3 x8
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+root, workload = sys.argv[1], sys.argv[2]
+LABEL = [  # kernel symbol (regex) -> the label of bench.py's per-kernel table
+    (r"k_rle<", "k_rle"),
+    (r"k_scatter<true, [^>]*, true>", "k_scatter<bases,y>"),
+    (r"k_scatter<true", "k_scatter<bases>"),
+    (r"k_scatter<false", "k_scatter<entries>"),
+    (r"k_hist_bases<true>", "k_hist_bases<y>"),
+    (r"k_hist_bases<false>", "k_hist_bases"),
+    (r"k_hist_entries", "k_hist_entries"),
+    (r"k_count_y_sorted", "k_count_y_sorted"),
+    (r"k_count_y_lds", "k_count_y_lds"),
+]
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
+                continue
+            for pat, lab in LABEL:
+                if re.search(pat, r["Kernel_Name"]):
+                    acc[lab][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    break
+out = {}
+for lab, c in acc.items():
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        fetch = 2.0 * 1024.0 * sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
+        write = 1024.0 * sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
+        out[lab] = {"bytes": int(fetch + write), "fetch_bytes": int(fetch), "write_bytes": int(write),
+                    "launches_sampled": len(c["FETCH_SIZE"])}
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kmers_amd", "data", "pmc_traffic.json")
+os.makedirs(os.path.dirname(path), exist_ok=True)
+allw = json.load(open(path)) if os.path.exists(path) else {}
+allw[workload] = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH doubled (gfx950), KiB -> bytes; "
+                            "mean per launch", "kernels": out}
+json.dump(allw, open(path, "w"), indent=1, sort_keys=True)
+print(json.dumps(allw[workload], indent=1))
