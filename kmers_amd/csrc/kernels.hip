@@ -457,26 +457,41 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
 
     ET e[IPT];
     uint32_t aux[IPT];   // narrow pass 1: the region (= previous digit) of each entry, found when the load is issued
-    uint32_t rhint = 0;
     TilePf pf;
+    // entries of tile t (the wave's 16 rounds) into e[]; narrow: their regions into aux[].  A wave's 1024 entries lie
+    // in one region nearly always (256 regions): one wave-uniform test instead of an LDS walk per entry.
+    auto load_tile = [&](uint32_t t) {
+        const uint32_t c0 = t * TILE + w * WCHUNK;  // the wave's first entry
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint64_t i = (uint64_t)c0 + j * 64 + lane;
+            e[j] = (i < E) ? in[i] : (ET)0;
+        }
+        if constexpr (NARROW) {
+            const uint32_t r0 = region_search(sreg, c0 < E ? c0 : (E ? E - 1u : 0u));  // wave-uniform
+            const bool one = sreg[r0 + 1] >= c0 + WCHUNK || sreg[r0 + 1] >= E;
+            if (one) {
+#pragma unroll
+                for (int j = 0; j < IPT; ++j) aux[j] = r0;
+            } else {
+                uint32_t r = r0;
+#pragma unroll
+                for (int j = 0; j < IPT; ++j) {
+                    const uint32_t i = c0 + j * 64 + lane;
+                    if (i < E) r = region_from(sreg, i, r);
+                    aux[j] = r;
+                }
+            }
+        }
+    };
     if (FROM_BASES) {
         pf = tile_fetch<!YKEYS>(a, t0);
     } else {
         if constexpr (NARROW) {
             for (uint32_t i = tid; i <= RADIX; i += NT) sreg[i] = regions[i];
             lds_sync();
-            const uint32_t i0 = t0 * TILE + w * WCHUNK;
-            rhint = region_search(sreg, i0 < E ? i0 : (E ? E - 1 : 0));
         }
-#pragma unroll
-        for (int j = 0; j < IPT; ++j) {
-            const uint64_t i = (uint64_t)t0 * TILE + w * WCHUNK + j * 64 + lane;
-            e[j] = (i < E) ? in[i] : (ET)0;
-            if constexpr (NARROW) {
-                if (i < E) rhint = region_from(sreg, (uint32_t)i, rhint);
-                aux[j] = rhint;
-            }
-        }
+        load_tile(t0);
     }
     uint32_t gb = (tid < RADIX) ? tilebase[(uint64_t)t0 * RADIX + tid] : 0u;
 
@@ -596,15 +611,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         if (!FROM_BASES && tile + 1 < t1 && !KK_ABLATE(2)) {  // e[] is free again: fetch the next tile behind the write-out
-#pragma unroll
-            for (int j = 0; j < IPT; ++j) {
-                const uint64_t i = base + TILE + w * WCHUNK + j * 64 + lane;
-                e[j] = (i < E) ? in[i] : (ET)0;
-                if constexpr (NARROW) {
-                    if (i < E) rhint = region_from(sreg, (uint32_t)i, rhint);
-                    aux[j] = rhint;
-                }
-            }
+            load_tile(tile + 1);
         }
         KK_STAMP(4);  // LDS scatter + prefetch issue
         lds_sync();
