@@ -222,12 +222,20 @@ def main():
                 "k_count_y_sorted": 4 * E + 8 * M,
             }
         dom = max((r for r in table if r[0] in kernel_bytes), key=lambda r: r[1], default=None)
+        # HBM traffic per launch measured with rocprofv3 PMC passes of this same command (tools/pmc.sh +
+        # tools/pmc_traffic.py; counters cannot be read from inside the process), default sizes only
+        traffic = None
+        default_size = (args.records, args.bases, args.reads) == (170_000, 400_000_000, 10_000_000)
+        tpath = os.path.join(ROOT, "kmers_amd", "data", "pmc_traffic.json")
+        if dom is not None and default_size and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(args.workload, {}).get("kernels", {}).get(dom[0], {}).get("bytes")
         roof = None
         if dom is not None:
             avg_ms = dom[1] / dom[2]
             ach = kernel_bytes[dom[0]] / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(avg_ms, 4),
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_ms": round(avg_ms, 4),
                     "launches_per_step": dom[2] // max(args.steps, 1), "algorithmic_bytes": int(kernel_bytes[dom[0]])}
         else:
             ach = path_bytes / (ms_per_step * 1e-3) / 1e9
