@@ -385,25 +385,33 @@ __global__ __launch_bounds__(NT) void k_hist_bases(BasesArgs a, uint32_t *tilehi
     }
 }
 
-// Later-pass histogram over stored entries.  One tile per workgroup; tiles past the entry count write zeros.
+// Later-pass histogram over stored entries.  Persistent: workgroup b walks a contiguous range of tiles and loads
+// tile t+1 while tile t is counted (two LDS tables: one is zeroed while the other is filled); tiles past the entry count get zeros.
 template <class ET>
 __global__ __launch_bounds__(NT) void k_hist_entries(const ET *ent, const uint32_t *p_count, int shift, uint32_t *tilehist,
                                                      uint32_t n_tiles) {
     constexpr bool NARROW = sizeof(ET) == 4;
-    __shared__ uint32_t h[NW][RADIX];
+    __shared__ uint32_t h[2][NW][RADIX];
     const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
-    const uint32_t tile = blockIdx.x;
     const uint32_t E = *p_count;
-    const uint64_t base = (uint64_t)tile * TILE;
-    for (uint32_t i = tid; i < NW * RADIX; i += NT) (&h[0][0])[i] = 0;
-    lds_sync();
-    if (base < E) {
-        ET e[IPT];
+    const uint32_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    if (t0 >= t1) return;
+    ET e[IPT];
+    auto load_tile = [&](uint32_t t) {
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
-            const uint64_t i = base + w * WCHUNK + j * 64 + lane;
+            const uint64_t i = (uint64_t)t * TILE + w * WCHUNK + j * 64 + lane;
             e[j] = (i < E) ? ent[i] : (ET)0;
         }
+    };
+    load_tile(t0);
+    for (uint32_t i = tid; i < NW * RADIX; i += NT) (&h[0][0][0])[i] = 0;
+    lds_sync();
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+        uint32_t(*const hc)[RADIX] = h[(tile - t0) & 1u];
+        uint32_t(*const hn)[RADIX] = h[((tile - t0) & 1u) ^ 1u];
+        const uint64_t base = (uint64_t)tile * TILE;
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             const uint64_t i = base + w * WCHUNK + j * 64 + lane;
@@ -412,15 +420,19 @@ __global__ __launch_bounds__(NT) void k_hist_entries(const ET *ent, const uint32
                 d = (uint32_t)e[j] >> 24;
             else
                 d = (entry_key((u64)e[j]) >> shift) & 255u;
-            if (i < E) atomicAdd(&h[w][d], 1u);
+            if (i < E) atomicAdd(&hc[w][d], 1u);
         }
-    }
-    lds_sync();
-    if (tid < RADIX) {
-        uint32_t s = 0;
+        if (tile + 1 < t1) load_tile(tile + 1);  // e[] is free again
+        for (uint32_t i = tid; i < NW * RADIX; i += NT) (&hn[0][0])[i] = 0;  // the other table, for the next tile
+        lds_sync();
+        if (tid < RADIX) {
+            uint32_t s = 0;
 #pragma unroll
-        for (int i = 0; i < NW; ++i) s += h[i][tid];
-        tilehist[(uint64_t)tile * RADIX + tid] = s;
+            for (int i = 0; i < NW; ++i) s += hc[i][tid];
+            tilehist[(uint64_t)tile * RADIX + tid] = s;
+        }
+        // the next tile zeroes hc right after its atomics (which go to hn): the readers above must be done first
+        lds_sync();
     }
 }
 
@@ -1512,7 +1524,7 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         pt.mark("k_scatter<bases,y>");
         const uint32_t *sorted = entA, *final_regions = regs0;
         if (two_pass) {
-            hipLaunchKernelGGL(k_hist_entries<uint32_t>, grid, block, 0, s, (const uint32_t *)entA, c_E, 8, hist, nt);
+            hipLaunchKernelGGL(k_hist_entries<uint32_t>, hgrid, block, 0, s, (const uint32_t *)entA, c_E, 8, hist, nt);
             pt.mark("k_hist_entries");
             if (int rc = scan_tilehist(hist, nt, bsum, &scal[4], s)) return rc;
             pt.mark("k_scan");
@@ -1596,7 +1608,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
                            ei, (const uint32_t *)nullptr);
         pt.mark("k_scatter<bases>");
         if (n_pass > 1) {
-            hipLaunchKernelGGL(k_hist_entries<uint32_t>, grid, block, 0, s, (const uint32_t *)ei, c_E, 8, hist, l.n_tiles);
+            hipLaunchKernelGGL(k_hist_entries<uint32_t>, hgrid, block, 0, s, (const uint32_t *)ei, c_E, 8, hist, l.n_tiles);
             pt.mark("k_hist_entries");
             if (int rc = scan_tilehist(hist, l.n_tiles, bsum, &scal[4], s)) return rc;
             pt.mark("k_scan");
