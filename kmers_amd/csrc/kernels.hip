@@ -245,6 +245,37 @@ __device__ __forceinline__ uint32_t record_at(const TileLds &L, uint32_t o) {
     return L.cb + L.spre[b] + (uint32_t)__popcll(f & upto) - 1u;
 }
 
+// Record lookup for a wave's rounds without per-lane LDS traffic: round j of wave w covers the 64 positions of flag
+// block w*IPT + j, so its two flag words and its record base are wave-uniform.  Lane l < IPT holds round l's values;
+// a round fetches them with v_readlane.  Nearly every block has no record start (a boundary every ~2400 positions):
+// then the whole round is one record.
+struct RecLanes {
+    uint32_t f_lo, f_hi, rb;  // flag words of block w*IPT + lane; records that start before it (tile base included)
+};
+__device__ __forceinline__ RecLanes rec_lanes_load(const TileLds &L, uint32_t w, uint32_t lane) {
+    RecLanes r{0u, 0u, 0u};
+    if (lane < (uint32_t)IPT) {
+        const uint32_t b = w * IPT + lane;
+        r.f_lo = L.sflag[2 * b];
+        r.f_hi = L.sflag[2 * b + 1];
+        r.rb = L.cb + L.spre[b];
+    }
+    return r;
+}
+// Local record index of this lane's position in round j (wave-uniform when the block has no record start).
+__device__ __forceinline__ uint32_t rec_lanes_at(const RecLanes &r, int j, uint32_t lane, u64 &f_out) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)r.f_lo, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)r.f_hi, j);
+    const uint32_t rb = (uint32_t)__builtin_amdgcn_readlane((int)r.rb, j);
+    const u64 f = ((u64)hi << 32) | lo;
+    f_out = f;
+    uint32_t rec = rb - 1u;
+    if (f) {  // wave-uniform branch
+        const u64 upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+        rec += (uint32_t)__popcll(f & upto);
+    }
+    return rec;
+}
+
 // bit p of rec_flags := a record starts at p.  rec_flags is zeroed beforehand.
 __global__ void k_mark_records(const uint64_t *rec_start, uint64_t n_rec, uint32_t *rec_flags) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -351,6 +382,8 @@ __global__ __launch_bounds__(NT) void k_hist_bases(BasesArgs a, uint32_t *tilehi
         for (uint32_t i = tid; i < NW * RADIX; i += NT) (&h[0][0])[i] = 0;
         tile_commit<!YKEYS>(L, pf, stmp);
         if (tile + 1 < t1) pf = tile_fetch<!YKEYS>(a, tile + 1);
+        RecLanes rl{0u, 0u, 0u};
+        if (!YKEYS) rl = rec_lanes_load(L, w, lane);
 #pragma unroll 2
         for (int j = 0; j < IPT; ++j) {
             const uint32_t o = w * WCHUNK + j * 64 + lane;
@@ -361,16 +394,20 @@ __global__ __launch_bounds__(NT) void k_hist_bases(BasesArgs a, uint32_t *tilehi
             // valid windows per record: lanes are position-ordered, so records form contiguous lane segments
             const u64 okm = YKEYS ? 0ull : __ballot(ok);
             if (okm) {
-                const uint32_t rec = record_at(L, o);
-                const uint32_t prev = __shfl_up(rec, 1);
-                const bool first = (lane == 0) || (rec != prev);
-                const u64 fm = __ballot(first);
-                if (first) {
-                    const u64 above = (lane == 63) ? 0ull : (fm & ~((2ull << lane) - 1ull));
-                    const uint32_t endl = above ? (uint32_t)__ffsll((long long)above) - 1u : 64u;
-                    const u64 seg = ((endl == 64) ? ~0ull : ((1ull << endl) - 1ull)) & ~lanes_below(lane);
-                    const uint32_t cnt = (uint32_t)__popcll(okm & seg);
-                    if (cnt) atomicAdd(&rec_total[rec], cnt);
+                u64 f;
+                const uint32_t rec = rec_lanes_at(rl, j, lane, f);
+                if ((f >> 1) == 0) {  // one record for the whole round (it may start at lane 0)
+                    if (lane == 0) atomicAdd(&rec_total[rec], (uint32_t)__popcll(okm));
+                } else {
+                    const bool first = (lane == 0) || ((f >> lane) & 1ull);
+                    const u64 fm = f | 1ull;  // segment starts
+                    if (first) {
+                        const u64 above = (lane == 63) ? 0ull : (fm & ~((2ull << lane) - 1ull));
+                        const uint32_t endl = above ? (uint32_t)__ffsll((long long)above) - 1u : 64u;
+                        const u64 seg = ((endl == 64) ? ~0ull : ((1ull << endl) - 1ull)) & ~lanes_below(lane);
+                        const uint32_t cnt = (uint32_t)__popcll(okm & seg);
+                        if (cnt) atomicAdd(&rec_total[rec], cnt);
+                    }
                 }
             }
         }
@@ -542,7 +579,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
                     col = key & ((1u << a.low_bits) - 1u);
                     key >>= a.low_bits;
                 } else {
-                    col = record_at(L, o);
+                    col = record_at(L, o);  // (the readlane variant of k_hist_bases costs 3 VGPRs here: spills, slower)
                 }
                 asm volatile("" : "+v"(col));  // finish the column now: sunk to its use it keeps 4 LDS words per round alive
                 if constexpr (NARROW) {
