@@ -216,10 +216,10 @@ def main():
                 "k_count_y_lds": n_pos * 3 / 8 * (2 if K == 8 else 1) + 4 * M,
                 "k_count_y_global": n_pos * 3 / 8 + 8 * E,
                 "k_hist_bases<y>": n_pos * 3 / 8,
-                "k_scatter<bases,y>": n_pos * 3 / 8 + 4 * E,
+                "k_scatter<bases,y>": n_pos * 3 / 8 + (2 if K <= 12 else 4) * E,   # 2-byte payloads with one pass
                 "k_hist_entries": 4 * E,
                 "k_scatter<entries>": 8 * E,
-                "k_count_y_sorted": 4 * E + 8 * M,
+                "k_count_y_sorted": (2 if K <= 12 else 4) * E + 8 * M,
             }
         dom = max((r for r in table if r[0] in kernel_bytes), key=lambda r: r[1], default=None)
         # HBM traffic per launch measured with rocprofv3 PMC passes of this same command (tools/pmc.sh +

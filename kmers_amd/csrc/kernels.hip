@@ -478,11 +478,16 @@ __global__ __launch_bounds__(NT) void k_hist_entries(const ET *ent, const uint32
 //   FROM_BASES: entries are generated from the packed store (pass 0); otherwise read from `in`.
 //   tilebase = exclusive scan of the digit-major tile histogram: global position of the first entry of (digit, tile).
 //   YKEYS (y for K >= 9, narrow entries from the bases): sort key = id >> low_bits, payload = the low bits, no records.
-template <bool FROM_BASES, class ET, bool YKEYS = false>
+//   ORDER_FREE (the y path): the entries of a (digit, tile) may land in any order -- a histogram follows, not a
+//   run-length reduce -- so the rank is simply what one returning LDS atomic on the tile's digit counter hands out.
+//   OUT16 (y, one pass, K <= 12): only the low 16 bits of an entry mean anything (the sort key is the region):
+//   `out` is an array of uint16_t.
+template <bool FROM_BASES, class ET, bool YKEYS = false, bool ORDER_FREE = false, bool OUT16 = false>
 __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, const uint32_t *p_count, int shift,
                                                    const uint32_t *tilebase, uint32_t n_tiles, ET *out, const uint32_t *regions) {
     constexpr bool NARROW = sizeof(ET) == 4;
     static_assert(!YKEYS || (FROM_BASES && NARROW), "y keys are generated from the bases as narrow entries");
+    static_assert(!ORDER_FREE || NARROW, "order-free partition is the y path's: narrow entries");
     // entry staging; its first NW*RADIX 8-byte words double as the match masks (below)
     __shared__ __attribute__((aligned(16))) ET sent[TILE];
     __shared__ uint8_t saux[NARROW ? TILE : 4];  // narrow: pass 0 the partition digit, pass 1 the byte that replaces it
@@ -547,9 +552,13 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
     KK_STAMP_BEGIN();
     for (uint32_t tile = t0; tile < t1; ++tile) {
         const uint64_t base = (uint64_t)tile * TILE;
-        for (uint32_t i = tid; i < NW * RADIX; i += NT) {
-            (&wcnt[0][0])[i] = 0;
-            smask[i] = 0ull;  // the match masks must start (and, by construction, end) a tile all zero
+        if (ORDER_FREE) {
+            if (tid < RADIX) wcnt[0][tid] = 0;
+        } else {
+            for (uint32_t i = tid; i < NW * RADIX; i += NT) {
+                (&wcnt[0][0])[i] = 0;
+                smask[i] = 0ull;  // the match masks must start (and, by construction, end) a tile all zero
+            }
         }
         if (FROM_BASES) {
             tile_commit<!YKEYS>(L, pf, stmp);
@@ -604,6 +613,12 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
             // order, so the read sees all 64 ORs; OR is order-independent, so the ranks are deterministic.  The lowest
             // lane of each group advances the (wave, digit) counter and clears the word for the next round.
             // (An 8-ballot match in registers gives the same masks for ~45 more VALU instructions per round.)
+            if constexpr (ORDER_FREE) {
+                uint32_t r = 0;
+                if (ok) r = atomicAdd(&wcnt[0][d], 1u);
+                rank[j] = ok ? (r | (ab << 16)) : NONE;
+                continue;
+            }
             u64 m = 0;
             uint32_t before = 0;
             if (ok) {
@@ -629,17 +644,25 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
         uint32_t dtot = 0;
         uint32_t wc[NW];
         if (tid < RADIX) {
+            if (ORDER_FREE) {
+                dtot = wcnt[0][tid];
+            } else {
 #pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                wc[i] = dtot;
-                dtot += wcnt[i][tid];
+                for (int i = 0; i < NW; ++i) {
+                    wc[i] = dtot;
+                    dtot += wcnt[i][tid];
+                }
             }
         }
         uint32_t tile_count;
         const uint32_t dstart = block_excl_scan(dtot, stmp, tile_count);
         if (tid < RADIX) {
+            if (ORDER_FREE) {
+                wcnt[0][tid] = dstart;
+            } else {
 #pragma unroll
-            for (int i = 0; i < NW; ++i) wcnt[i][tid] = dstart + wc[i];
+                for (int i = 0; i < NW; ++i) wcnt[i][tid] = dstart + wc[i];
+            }
             gadj[tid] = gb - dstart;
             if (tile + 1 < t1) gb = tilebase[(uint64_t)(tile + 1) * RADIX + tid];
         }
@@ -653,7 +676,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
                     d = FROM_BASES ? ((rank[j] >> 16) & 255u) : ((uint32_t)e[j] >> 24);
                 else
                     d = __builtin_amdgcn_ubfe(entry_key((u64)e[j]), (uint32_t)shift, 8u);
-                const uint32_t slot = wrow[d] + (rank[j] & 0xFFFFu);
+                const uint32_t slot = (ORDER_FREE ? wcnt[0][d] : wrow[d]) + (rank[j] & 0xFFFFu);
                 sent[slot] = e[j];
                 if constexpr (NARROW) saux[slot] = (uint8_t)(rank[j] >> 16);
             }
@@ -679,7 +702,11 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
             } else {
                 d = __builtin_amdgcn_ubfe(entry_key((u64)v), (uint32_t)shift, 8u);
             }
-            if (!KK_ABLATE(1)) out[gadj[d] + i] = v;
+            if (KK_ABLATE(1)) continue;
+            if constexpr (OUT16)
+                reinterpret_cast<uint16_t *>(out)[gadj[d] + i] = (uint16_t)v;
+            else
+                out[gadj[d] + i] = v;
         }
         KK_STAMP(6);  // write-out
         lds_sync();
@@ -766,18 +793,25 @@ __device__ __forceinline__ void ys_add(uint32_t *h, uint32_t bin) {
 }
 
 // Count entries [begin, end) into h.  All YS_NT threads call it with the same arguments.
-template <uint32_t NB>
-__device__ __forceinline__ void ys_count_range(uint32_t *h, const uint32_t *ent, uint32_t begin, uint32_t end, const YSlice &y) {
+// ET = uint32_t: (sort-key byte << 24 | low bits); ET = uint16_t (one pass, K <= 12): the low bits alone.
+template <uint32_t NB, class ET>
+__device__ __forceinline__ void ys_count_range(uint32_t *h, const ET *ent, uint32_t begin, uint32_t end, const YSlice &y) {
     const uint32_t tid = threadIdx.x;
-    auto bin_of = [&](uint32_t v) { return ((((v >> 24) - y.c_lo) << y.low_bits) | (v & y.low_mask)) - y.sub0; };
+    constexpr uint32_t PER = 16 / sizeof(ET);  // entries per 16-byte load
+    auto bin_of = [&](uint32_t v) {
+        if constexpr (sizeof(ET) == 2)
+            return v - y.sub0;
+        else
+            return ((((v >> 24) - y.c_lo) << y.low_bits) | (v & y.low_mask)) - y.sub0;
+    };
     // 16-byte loads over the aligned body, YS_UNROLL of them in flight per lane; the ragged ends one entry at a time
-    const uint32_t a0 = (begin + 3u) & ~3u, a1 = end & ~3u;
+    const uint32_t a0 = (begin + PER - 1u) & ~(PER - 1u), a1 = end & ~(PER - 1u);
     if (a0 < a1) {
         ys_add<NB>(h, (begin + tid < a0) ? bin_of(ent[begin + tid]) : NONE);
         ys_add<NB>(h, (a1 + tid < end) ? bin_of(ent[a1 + tid]) : NONE);
         const uint4 *ent4 = reinterpret_cast<const uint4 *>(ent);
-        const uint32_t q1 = a1 >> 2;
-        for (uint32_t qb = a0 >> 2; qb < q1; qb += YS_NT * YS_UNROLL) {  // wave-uniform trip count
+        const uint32_t q1 = a1 / PER;
+        for (uint32_t qb = a0 / PER; qb < q1; qb += YS_NT * YS_UNROLL) {  // wave-uniform trip count
             uint4 v[YS_UNROLL];
 #pragma unroll
             for (int u = 0; u < YS_UNROLL; ++u) {
@@ -787,10 +821,16 @@ __device__ __forceinline__ void ys_count_range(uint32_t *h, const uint32_t *ent,
 #pragma unroll
             for (int u = 0; u < YS_UNROLL; ++u) {
                 const bool in = qb + u * YS_NT + tid < q1;
-                ys_add<NB>(h, in ? bin_of(v[u].x) : NONE);
-                ys_add<NB>(h, in ? bin_of(v[u].y) : NONE);
-                ys_add<NB>(h, in ? bin_of(v[u].z) : NONE);
-                ys_add<NB>(h, in ? bin_of(v[u].w) : NONE);
+                const uint32_t word[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if constexpr (sizeof(ET) == 2) {
+                        ys_add<NB>(h, in ? bin_of(word[c] & 0xFFFFu) : NONE);
+                        ys_add<NB>(h, in ? bin_of(word[c] >> 16) : NONE);
+                    } else {
+                        ys_add<NB>(h, in ? bin_of(word[c]) : NONE);
+                    }
+                }
             }
         }
     } else {
@@ -804,8 +844,8 @@ struct YOverflow {
 
 // One workgroup per slice.  A slice with more than `cap` entries (a hot bucket: poly-A) keeps its first `cap` and
 // queues the rest for k_count_y_overflow, which spreads it over many workgroups.
-template <int BPB_LOG2>
-__global__ __launch_bounds__(YS_NT) void k_count_y_sorted(const uint32_t *ent, const uint32_t *regions, int two_pass, int low_bits,
+template <int BPB_LOG2, class ET>
+__global__ __launch_bounds__(YS_NT) void k_count_y_sorted(const ET *ent, const uint32_t *regions, int two_pass, int low_bits,
                                                           int32_t *counts, uint32_t cap, uint32_t *ovf_count, YOverflow *ovf,
                                                           uint32_t ovf_cap) {
     constexpr uint32_t NB = 1u << BPB_LOG2;
@@ -819,13 +859,17 @@ __global__ __launch_bounds__(YS_NT) void k_count_y_sorted(const uint32_t *ent, c
     } else {
         const uint32_t r = y.k_lo >> 8;
         const uint32_t rb = regions[r], re = regions[r + 1];
-        if (w == 0) {
-            const uint32_t b = wave_lower_bound_byte(ent, rb, re, y.c_lo);
-            if (lane_id() == 0) s_range[0] = b;
-        } else if (w == 1) {
-            const uint32_t c_hi = y.c_lo + y.nk;
-            const uint32_t e = (c_hi > 255u) ? re : wave_lower_bound_byte(ent, rb, re, c_hi);
-            if (lane_id() == 0) s_range[1] = e;
+        if constexpr (sizeof(ET) == 4) {  // (two passes always store 4-byte entries)
+            if (w == 0) {
+                const uint32_t b = wave_lower_bound_byte(ent, rb, re, y.c_lo);
+                if (lane_id() == 0) s_range[0] = b;
+            } else if (w == 1) {
+                const uint32_t c_hi = y.c_lo + y.nk;
+                const uint32_t e = (c_hi > 255u) ? re : wave_lower_bound_byte(ent, rb, re, c_hi);
+                if (lane_id() == 0) s_range[1] = e;
+            }
+        } else if (tid < 2) {
+            s_range[tid] = tid ? re : rb;
         }
     }
     lds_sync();
@@ -843,7 +887,7 @@ __global__ __launch_bounds__(YS_NT) void k_count_y_sorted(const uint32_t *ent, c
         lds_sync();
         end = s_range[1];
     }
-    ys_count_range<NB>(h, ent, begin, end, y);
+    ys_count_range<NB, ET>(h, ent, begin, end, y);
     lds_sync();
     for (uint32_t i = tid; i < NB; i += YS_NT) {
         const uint32_t c = h[i];
@@ -853,8 +897,8 @@ __global__ __launch_bounds__(YS_NT) void k_count_y_sorted(const uint32_t *ent, c
 
 // The queued remainders, YS_OVF_CHUNK entries per workgroup pass, chunks dealt round-robin over the grid; these
 // share their bins with other workgroups, so they add to `counts` with atomics (non-zero bins only).
-template <int BPB_LOG2>
-__global__ __launch_bounds__(YS_NT) void k_count_y_overflow(const uint32_t *ent, int two_pass, int low_bits, int32_t *counts,
+template <int BPB_LOG2, class ET>
+__global__ __launch_bounds__(YS_NT) void k_count_y_overflow(const ET *ent, int two_pass, int low_bits, int32_t *counts,
                                                             const uint32_t *ovf_count, const YOverflow *ovf, uint32_t ovf_cap) {
     constexpr uint32_t NB = 1u << BPB_LOG2;
     __shared__ uint32_t h[NB];
@@ -872,7 +916,7 @@ __global__ __launch_bounds__(YS_NT) void k_count_y_overflow(const uint32_t *ent,
             const uint32_t e = (it.end - b > YS_OVF_CHUNK) ? b + YS_OVF_CHUNK : it.end;
             for (uint32_t j = tid; j < NB; j += YS_NT) h[j] = 0;
             lds_sync();
-            ys_count_range<NB>(h, ent, b, e, y);
+            ys_count_range<NB, ET>(h, ent, b, e, y);
             lds_sync();
             for (uint32_t j = tid; j < NB; j += YS_NT) {
                 const uint32_t c = h[j];
@@ -1470,12 +1514,12 @@ size_t y_workspace_bytes(uint64_t n_pos, int K) {
     return y_layout_for(y_default_chunk_tiles(n_pos), K).bytes;
 }
 
-template <int BPB_LOG2>
-static void launch_y_sorted(uint32_t blocks, hipStream_t s, const uint32_t *ent, const uint32_t *regions, int two_pass, int low_bits,
+template <int BPB_LOG2, class ET>
+static void launch_y_sorted(uint32_t blocks, hipStream_t s, const ET *ent, const uint32_t *regions, int two_pass, int low_bits,
                             int32_t *counts, uint32_t cap, uint32_t *ovf_count, YOverflow *ovf, uint32_t ovf_cap) {
-    hipLaunchKernelGGL(k_count_y_sorted<BPB_LOG2>, dim3(blocks), dim3(YS_NT), 0, s, ent, regions, two_pass, low_bits, counts, cap,
-                       ovf_count, ovf, ovf_cap);
-    hipLaunchKernelGGL(k_count_y_overflow<BPB_LOG2>, dim3(1024), dim3(YS_NT), 0, s, ent, two_pass, low_bits, counts,
+    hipLaunchKernelGGL((k_count_y_sorted<BPB_LOG2, ET>), dim3(blocks), dim3(YS_NT), 0, s, ent, regions, two_pass, low_bits, counts,
+                       cap, ovf_count, ovf, ovf_cap);
+    hipLaunchKernelGGL((k_count_y_overflow<BPB_LOG2, ET>), dim3(1024), dim3(YS_NT), 0, s, ent, two_pass, low_bits, counts,
                        (const uint32_t *)ovf_count, (const YOverflow *)ovf, ovf_cap);
 }
 
@@ -1556,8 +1600,12 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         if (int rc = scan_tilehist(hist, nt, bsum, &scal[0], s)) return rc;
         pt.mark("k_scan");
         hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, nt, c_E, regs0);
-        hipLaunchKernelGGL((k_scatter<true, uint32_t, true>), pgrid, block, 0, s, a, (const uint32_t *)nullptr, c_E, 0, c_hist, nt, entA,
-                           (const uint32_t *)nullptr);
+        if (two_pass)
+            hipLaunchKernelGGL((k_scatter<true, uint32_t, true, true, false>), pgrid, block, 0, s, a, (const uint32_t *)nullptr, c_E, 0,
+                               c_hist, nt, entA, (const uint32_t *)nullptr);
+        else  // one pass: 2-byte payloads
+            hipLaunchKernelGGL((k_scatter<true, uint32_t, true, true, true>), pgrid, block, 0, s, a, (const uint32_t *)nullptr, c_E, 0,
+                               c_hist, nt, entA, (const uint32_t *)nullptr);
         pt.mark("k_scatter<bases,y>");
         const uint32_t *sorted = entA, *final_regions = regs0;
         if (two_pass) {
@@ -1566,17 +1614,24 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
             if (int rc = scan_tilehist(hist, nt, bsum, &scal[4], s)) return rc;
             pt.mark("k_scan");
             hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, nt, c_E, regs1);
+            // this pass stays stable: k_count_y_sorted searches a region by the byte pass 0 sorted on
             hipLaunchKernelGGL((k_scatter<false, uint32_t>), pgrid, block, 0, s, a, (const uint32_t *)entA, c_E, 8, c_hist, nt, entB,
                                (const uint32_t *)regs0);
             pt.mark("k_scatter<entries>");
             sorted = entB;
             final_regions = regs1;
         }
-        switch (l.slice_log2) {
-            case 10: launch_y_sorted<10>(slices, s, sorted, final_regions, two_pass, low_bits, d_counts, cap, &scal[8], ovf, slices); break;
-            case 12: launch_y_sorted<12>(slices, s, sorted, final_regions, two_pass, low_bits, d_counts, cap, &scal[8], ovf, slices); break;
-            case 14: launch_y_sorted<14>(slices, s, sorted, final_regions, two_pass, low_bits, d_counts, cap, &scal[8], ovf, slices); break;
-            default: launch_y_sorted<15>(slices, s, sorted, final_regions, two_pass, low_bits, d_counts, cap, &scal[8], ovf, slices); break;
+        const uint16_t *sorted16 = (const uint16_t *)entA;
+        switch (l.slice_log2) {  // one pass: 10, 12, 14 or 15 (2-byte entries); two passes: 15 (4-byte entries)
+            case 10: launch_y_sorted<10>(slices, s, sorted16, final_regions, 0, low_bits, d_counts, cap, &scal[8], ovf, slices); break;
+            case 12: launch_y_sorted<12>(slices, s, sorted16, final_regions, 0, low_bits, d_counts, cap, &scal[8], ovf, slices); break;
+            case 14: launch_y_sorted<14>(slices, s, sorted16, final_regions, 0, low_bits, d_counts, cap, &scal[8], ovf, slices); break;
+            default:
+                if (two_pass)
+                    launch_y_sorted<15>(slices, s, sorted, final_regions, 1, low_bits, d_counts, cap, &scal[8], ovf, slices);
+                else
+                    launch_y_sorted<15>(slices, s, sorted16, final_regions, 0, low_bits, d_counts, cap, &scal[8], ovf, slices);
+                break;
         }
         pt.mark("k_count_y_sorted");
     }
