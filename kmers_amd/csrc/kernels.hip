@@ -325,39 +325,71 @@ __global__ __launch_bounds__(NT) void k_count_y_global(BasesArgs a, int32_t *cou
     }
 }
 
-// Tables of up to 32768 bins per sweep are privatised in LDS (u32 bins, no overflow) and flushed once per
-// workgroup: K <= 7 in one sweep; K = 8 in two sweeps over the tile range (bins [0,32768) then [32768,65536)):
-// the packed bases are 3 bits per position, so reading them twice costs far less than 4e8 contended global atomics.
-__global__ __launch_bounds__(NT) void k_count_y_lds(BasesArgs a, int32_t *counts, uint64_t n_tiles, uint32_t n_bins) {
-    __shared__ TileLds L;
-    __shared__ uint32_t stmp[NW];
+// ---- order-free window decode: a histogram does not care in which order windows arrive, so a thread takes the 16
+// consecutive windows that start in ONE packed word (positions 16 g .. 16 g + 15) and shifts them out of registers:
+// no LDS tile, no barrier, two VALU instructions per k-mer id.
+struct WordWindows {
+    uint32_t b0, b1;  // bases words g, g + 1 (a window of K <= 16 positions never reaches word g + 2)
+    uint32_t v;       // validity of positions 16 g .. 16 g + 31
+};
+__device__ __forceinline__ WordWindows word_fetch(const BasesArgs &a, uint64_t g) {
+    WordWindows x;
+    x.b0 = (g < a.bases_words) ? a.bases[g] : 0u;
+    x.b1 = (g + 1 < a.bases_words) ? a.bases[g + 1] : 0u;
+    const uint64_t vi = g >> 1;  // valid word of position 16 g
+    const uint32_t v0 = (vi < a.valid_words) ? a.valid[vi] : 0u, v1 = (vi + 1 < a.valid_words) ? a.valid[vi + 1] : 0u;
+    x.v = (g & 1) ? ((v0 >> 16) | (v1 << 16)) : v0;
+    return x;
+}
+// window j (0..15) of the word: valid iff its K positions are; key = the reference's k-mer id
+__device__ __forceinline__ bool word_window(const WordWindows &x, int j, int K, uint32_t &key) {
+    const uint32_t need = (1u << K) - 1u;  // K <= 16
+    const bool ok = ((x.v >> j) & need) == need;
+    const uint32_t top = j ? __builtin_amdgcn_alignbit(x.b0, x.b1, 32u - 2u * (uint32_t)j) : x.b0;  // 32 bits from base j on
+    key = top >> (32u - 2u * (uint32_t)K);
+    return ok;
+}
+
+// y, K <= 8: tables of up to 32768 bins per sweep are privatised in LDS (u32 bins, no overflow) and flushed once per
+// workgroup: K <= 7 in one sweep; K = 8 in two sweeps over the store (bins [0,32768) then [32768,65536)): the packed
+// bases are 3 bits per position, so reading them twice costs far less than 4e8 contended global atomics.
+// A thread adds a run of equal consecutive k-mers (poly-A) once, with its length.
+constexpr int YL_NT = 1024;
+__global__ __launch_bounds__(YL_NT) void k_count_y_lds(BasesArgs a, int32_t *counts, uint64_t n_words, uint32_t n_bins) {
     __shared__ uint32_t h[32768];
-    const uint32_t w = threadIdx.x >> 6, lane = lane_id();
     const uint32_t sweep_bins = n_bins < 32768u ? n_bins : 32768u;
+    const int K = a.K;
     for (uint32_t lo = 0; lo < n_bins; lo += sweep_bins) {
-        for (uint32_t i = threadIdx.x; i < sweep_bins; i += NT) h[i] = 0;
-        lds_sync();
-        uint64_t tile = blockIdx.x;
-        TilePf pf = tile_fetch<false>(a, tile < n_tiles ? tile : 0);
-        for (; tile < n_tiles; tile += gridDim.x) {
-            tile_commit<false>(L, pf, stmp);
-            if (tile + gridDim.x < n_tiles) pf = tile_fetch<false>(a, tile + gridDim.x);
-#pragma unroll 4
-            for (int j = 0; j < IPT; ++j) {
-                const uint32_t o = w * WCHUNK + j * 64 + lane;
+        for (uint32_t i = threadIdx.x; i < sweep_bins; i += YL_NT) h[i] = 0;
+        __syncthreads();
+        const uint64_t stride = (uint64_t)gridDim.x * YL_NT;
+        uint64_t g = (uint64_t)blockIdx.x * YL_NT + threadIdx.x;
+        WordWindows nx = word_fetch(a, g);
+        for (; g < n_words; g += stride) {
+            const WordWindows x = nx;
+            if (g + stride < n_words) nx = word_fetch(a, g + stride);
+            uint32_t run_bin = NONE, run_len = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
                 uint32_t key;
-                if (window_at(L, o, a.K, key)) {
-                    const uint32_t b = key - lo;
-                    if (b < sweep_bins) atomicAdd(&h[b], 1u);
+                const bool ok = word_window(x, j, K, key);
+                const uint32_t b = ok ? key - lo : NONE;  // >= sweep_bins: not in this sweep (or no k-mer)
+                if (b == run_bin) {
+                    ++run_len;
+                } else {
+                    if (run_bin < sweep_bins) atomicAdd(&h[run_bin], run_len);
+                    run_bin = b;
+                    run_len = 1;
                 }
             }
-            lds_sync();
+            if (run_bin < sweep_bins) atomicAdd(&h[run_bin], run_len);
         }
-        for (uint32_t i = threadIdx.x; i < sweep_bins; i += NT) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < sweep_bins; i += YL_NT) {
             const uint32_t v = h[i];
             if (v) atomicAdd(&counts[lo + i], (int32_t)v);
         }
-        lds_sync();
+        __syncthreads();
     }
 }
 
@@ -1531,8 +1563,10 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     PhaseTimer pt(s);
     if (K <= 8) {
         const uint32_t n_bins = 1u << (2 * K);
-        const uint32_t grid = (uint32_t)(n_tiles < 256 ? n_tiles : 256);  // 128 KiB of LDS: one workgroup per CU
-        hipLaunchKernelGGL(k_count_y_lds, dim3(grid), dim3(NT), 0, s, a, d_counts, n_tiles, n_bins);
+        const uint64_t n_words = (n_pos + 15) / 16;
+        const uint64_t wg = (n_words + YL_NT - 1) / YL_NT;
+        const uint32_t grid = (uint32_t)(wg < 256 ? wg : 256);  // 128 KiB of LDS: one workgroup per CU
+        hipLaunchKernelGGL(k_count_y_lds, dim3(grid), dim3(YL_NT), 0, s, a, d_counts, n_words, n_bins);
         pt.mark("k_count_y_lds");
         KK_CHECK(hipGetLastError());
         if (pt.on) {
