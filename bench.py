@@ -215,7 +215,7 @@ def main():
             kernel_bytes = {
                 "k_count_y_lds": n_pos * 3 / 8 * (2 if K == 8 else 1) + 4 * M,
                 "k_count_y_global": n_pos * 3 / 8 + 8 * E,
-                "k_hist_bases<y>": n_pos * 3 / 8,
+                "k_hist_words_y": n_pos * 3 / 8,
                 "k_scatter<bases,y>": n_pos * 3 / 8 + (2 if K <= 12 else 4) * E,   # 2-byte payloads with one pass
                 "k_hist_entries": 4 * E,
                 "k_scatter<entries>": 8 * E,

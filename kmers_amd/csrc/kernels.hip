@@ -399,8 +399,6 @@ __global__ __launch_bounds__(YL_NT) void k_count_y_lds(BasesArgs a, int32_t *cou
 
 // Pass 0 histogram, straight from the packed bases.  Also accumulates the number of valid windows per record
 // (the reference's total_count, src/libkmers.cpp:220-227) with one atomic per (wave round, record).
-// YKEYS (y for K >= 9): the digit is taken from the sort key id >> low_bits and there are no records.
-template <bool YKEYS>
 __global__ __launch_bounds__(NT) void k_hist_bases(BasesArgs a, uint32_t *tilehist, uint32_t n_tiles, uint32_t *rec_total) {
     __shared__ TileLds L;
     __shared__ uint32_t stmp[NW];
@@ -409,22 +407,20 @@ __global__ __launch_bounds__(NT) void k_hist_bases(BasesArgs a, uint32_t *tilehi
     const uint32_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
     const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
     if (t0 >= t1) return;
-    TilePf pf = tile_fetch<!YKEYS>(a, t0);
+    TilePf pf = tile_fetch<true>(a, t0);
     for (uint32_t tile = t0; tile < t1; ++tile) {
         for (uint32_t i = tid; i < NW * RADIX; i += NT) (&h[0][0])[i] = 0;
-        tile_commit<!YKEYS>(L, pf, stmp);
-        if (tile + 1 < t1) pf = tile_fetch<!YKEYS>(a, tile + 1);
-        RecLanes rl{0u, 0u, 0u};
-        if (!YKEYS) rl = rec_lanes_load(L, w, lane);
+        tile_commit<true>(L, pf, stmp);
+        if (tile + 1 < t1) pf = tile_fetch<true>(a, tile + 1);
+        const RecLanes rl = rec_lanes_load(L, w, lane);
 #pragma unroll 2
         for (int j = 0; j < IPT; ++j) {
             const uint32_t o = w * WCHUNK + j * 64 + lane;
             uint32_t key;
             const bool ok = window_at(L, o, a.K, key);
-            if (YKEYS) key >>= a.low_bits;
             if (ok) atomicAdd(&h[w][key & 255u], 1u);
             // valid windows per record: lanes are position-ordered, so records form contiguous lane segments
-            const u64 okm = YKEYS ? 0ull : __ballot(ok);
+            const u64 okm = __ballot(ok);
             if (okm) {
                 u64 f;
                 const uint32_t rec = rec_lanes_at(rl, j, lane, f);
@@ -451,6 +447,49 @@ __global__ __launch_bounds__(NT) void k_hist_bases(BasesArgs a, uint32_t *tilehi
             tilehist[(uint64_t)tile * RADIX + tid] = s;
         }
         lds_sync();
+    }
+}
+
+// y for K >= 9, pass 0 histogram: digit = low byte of the sort key id >> low_bits, per tile of 8192 positions
+// (= NT packed words, one per thread, decoded from registers: the order inside a tile does not matter here).
+__global__ __launch_bounds__(NT) void k_hist_words_y(BasesArgs a, uint32_t *tilehist, uint32_t n_tiles) {
+    __shared__ uint32_t h[2][NW][RADIX];
+    const uint32_t tid = threadIdx.x, w = tid >> 6;
+    const uint32_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    if (t0 >= t1) return;
+    WordWindows nx = word_fetch(a, (a.tile0 + t0) * NT + tid);
+    for (uint32_t i = tid; i < NW * RADIX; i += NT) (&h[0][0][0])[i] = 0;
+    lds_sync();
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+        uint32_t(*const hc)[RADIX] = h[(tile - t0) & 1u];
+        uint32_t(*const hn)[RADIX] = h[((tile - t0) & 1u) ^ 1u];
+        const WordWindows x = nx;
+        if (tile + 1 < t1) nx = word_fetch(a, (a.tile0 + tile + 1) * NT + tid);
+        uint32_t run_d = NONE, run_len = 0;  // equal consecutive digits (poly-A) are added once
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            uint32_t key;
+            const bool ok = word_window(x, j, a.K, key);
+            const uint32_t d = ok ? ((key >> a.low_bits) & 255u) : NONE;
+            if (d == run_d) {
+                ++run_len;
+            } else {
+                if (run_d != NONE) atomicAdd(&hc[w][run_d], run_len);
+                run_d = d;
+                run_len = 1;
+            }
+        }
+        if (run_d != NONE) atomicAdd(&hc[w][run_d], run_len);
+        for (uint32_t i = tid; i < NW * RADIX; i += NT) (&hn[0][0])[i] = 0;  // the other table, for the next tile
+        lds_sync();
+        if (tid < RADIX) {
+            uint32_t s = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) s += hc[i][tid];
+            tilehist[(uint64_t)tile * RADIX + tid] = s;
+        }
+        lds_sync();  // the next tile zeroes hc right after its atomics: the readers above must be done first
     }
 }
 
@@ -518,7 +557,8 @@ template <bool FROM_BASES, class ET, bool YKEYS = false, bool ORDER_FREE = false
 __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, const uint32_t *p_count, int shift,
                                                    const uint32_t *tilebase, uint32_t n_tiles, ET *out, const uint32_t *regions) {
     constexpr bool NARROW = sizeof(ET) == 4;
-    static_assert(!YKEYS || (FROM_BASES && NARROW), "y keys are generated from the bases as narrow entries");
+    static_assert(!YKEYS || (FROM_BASES && NARROW && ORDER_FREE), "y keys: from the bases, narrow entries, any order");
+    static_assert(IPT == 16, "one packed word (16 windows) per thread and tile");
     static_assert(!ORDER_FREE || NARROW, "order-free partition is the y path's: narrow entries");
     // entry staging; its first NW*RADIX 8-byte words double as the match masks (below)
     __shared__ __attribute__((aligned(16))) ET sent[TILE];
@@ -544,6 +584,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
     ET e[IPT];
     uint32_t aux[IPT];   // narrow pass 1: the region (= previous digit) of each entry, found when the load is issued
     TilePf pf;
+    WordWindows ww{0u, 0u, 0u};  // YKEYS: this thread's packed word of the next tile (windows decoded from registers)
     // entries of tile t (the wave's 16 rounds) into e[]; narrow: their regions into aux[].  A wave's 1024 entries lie
     // in one region nearly always (256 regions): one wave-uniform test instead of an LDS walk per entry.
     auto load_tile = [&](uint32_t t) {
@@ -570,8 +611,10 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
             }
         }
     };
-    if (FROM_BASES) {
-        pf = tile_fetch<!YKEYS>(a, t0);
+    if (YKEYS) {
+        ww = word_fetch(a, (a.tile0 + t0) * NT + tid);
+    } else if (FROM_BASES) {
+        pf = tile_fetch<true>(a, t0);
     } else {
         if constexpr (NARROW) {
             for (uint32_t i = tid; i <= RADIX; i += NT) sreg[i] = regions[i];
@@ -592,9 +635,13 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
                 smask[i] = 0ull;  // the match masks must start (and, by construction, end) a tile all zero
             }
         }
-        if (FROM_BASES) {
-            tile_commit<!YKEYS>(L, pf, stmp);
-            if (tile + 1 < t1) pf = tile_fetch<!YKEYS>(a, tile + 1);
+        WordWindows wcur = ww;
+        if (YKEYS) {
+            if (tile + 1 < t1) ww = word_fetch(a, (a.tile0 + tile + 1) * NT + tid);
+            lds_sync();
+        } else if (FROM_BASES) {
+            tile_commit<true>(L, pf, stmp);
+            if (tile + 1 < t1) pf = tile_fetch<true>(a, tile + 1);
         } else {
             lds_sync();
         }
@@ -614,12 +661,13 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
             if (FROM_BASES) {
                 const uint32_t o = wl + j * 64;
                 uint32_t key;
-                ok = window_at(L, o, a.K, key);
                 uint32_t col;
-                if constexpr (YKEYS) {
+                if constexpr (YKEYS) {  // window j of this thread's word: any order will do
+                    ok = word_window(wcur, j, a.K, key);
                     col = key & ((1u << a.low_bits) - 1u);
                     key >>= a.low_bits;
                 } else {
+                    ok = window_at(L, o, a.K, key);
                     col = record_at(L, o);  // (the readlane variant of k_hist_bases costs 3 VGPRs here: spills, slower)
                 }
                 asm volatile("" : "+v"(col));  // finish the column now: sunk to its use it keeps 4 LDS words per round alive
@@ -1629,8 +1677,8 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         const dim3 pgrid(nt < (uint32_t)PERSIST_BLOCKS ? nt : (uint32_t)PERSIST_BLOCKS);
         const dim3 hgrid(nt < 2048u ? nt : 2048u);
         const uint32_t *c_hist = hist, *c_E = &scal[0];
-        hipLaunchKernelGGL(k_hist_bases<true>, hgrid, block, 0, s, a, hist, nt, (uint32_t *)nullptr);
-        pt.mark("k_hist_bases<y>");
+        hipLaunchKernelGGL(k_hist_words_y, hgrid, block, 0, s, a, hist, nt);
+        pt.mark("k_hist_words_y");
         if (int rc = scan_tilehist(hist, nt, bsum, &scal[0], s)) return rc;
         pt.mark("k_scan");
         hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, nt, c_E, regs0);
@@ -1722,7 +1770,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     const uint32_t *c_hist = hist, *c_E = &scal[0];
 
     // pass 0: packed bases -> instances partitioned by the lowest digit
-    hipLaunchKernelGGL(k_hist_bases<false>, hgrid, block, 0, s, a, hist, l.n_tiles, total);
+    hipLaunchKernelGGL(k_hist_bases, hgrid, block, 0, s, a, hist, l.n_tiles, total);
     pt.mark("k_hist_bases");
     if (int rc = scan_tilehist(hist, l.n_tiles, bsum, &scal[0], s)) return rc;
     pt.mark("k_scan");

@@ -19,8 +19,8 @@ LABEL = [  # kernel symbol (regex) -> the label of bench.py's per-kernel table
     (r"k_scatter<true, [^>]*, true>", "k_scatter<bases,y>"),
     (r"k_scatter<true", "k_scatter<bases>"),
     (r"k_scatter<false", "k_scatter<entries>"),
-    (r"k_hist_bases<true>", "k_hist_bases<y>"),
-    (r"k_hist_bases<false>", "k_hist_bases"),
+    (r"k_hist_words_y", "k_hist_words_y"),
+    (r"k_hist_bases", "k_hist_bases"),
     (r"k_hist_entries", "k_hist_entries"),
     (r"k_count_y_sorted", "k_count_y_sorted"),
     (r"k_count_y_lds", "k_count_y_lds"),
