@@ -854,26 +854,11 @@ __device__ __forceinline__ YSlice ys_slice(uint32_t slice, int two_pass, int low
     return y;
 }
 
-// h[bin] += 1 for every lane whose bin is < NB -- but equal bins in consecutive lanes are added once, with the run
-// length: reads are full of homopolymer runs (poly-A tails: 0.7 % of the bench's windows are one k-mer), and 64
-// same-address LDS atomics serialise.  ALL 64 lanes must call it (lanes without an entry pass NONE).
-template <uint32_t NB>
-__device__ __forceinline__ void ys_add(uint32_t *h, uint32_t bin) {
-    const uint32_t key = bin < NB ? bin : NONE;
-    // previous lane's key (wave_shr:1); lane 0 keeps `old` = ~key, which differs from key
-    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x138, 0xF, 0xF, false);
-    const bool head = key != prev;
-    const u64 hm = __ballot(head);
-    if (head && key != NONE) {
-        const uint32_t lane = lane_id();
-        const u64 above = (hm >> lane) >> 1;  // heads in the lanes after this one
-        const uint32_t len = above ? (uint32_t)__ffsll((long long)above) : 64u - lane;
-        atomicAdd(&h[key], len);
-    }
-}
-
 // Count entries [begin, end) into h.  All YS_NT threads call it with the same arguments.
 // ET = uint32_t: (sort-key byte << 24 | low bits); ET = uint16_t (one pass, K <= 12): the low bits alone.
+// A thread adds a run of equal consecutive entries (poly-A: 0.7 % of the bench's windows are one k-mer, and 64
+// same-address LDS atomics serialise) once, with its length -- entries of one 16-byte load are consecutive in the
+// partitioned array, which keeps position order inside a (digit, tile) group closely enough for runs to survive.
 template <uint32_t NB, class ET>
 __device__ __forceinline__ void ys_count_range(uint32_t *h, const ET *ent, uint32_t begin, uint32_t end, const YSlice &y) {
     const uint32_t tid = threadIdx.x;
@@ -884,14 +869,17 @@ __device__ __forceinline__ void ys_count_range(uint32_t *h, const ET *ent, uint3
         else
             return ((((v >> 24) - y.c_lo) << y.low_bits) | (v & y.low_mask)) - y.sub0;
     };
+    auto add1 = [&](uint32_t bin) {
+        if (bin < NB) atomicAdd(&h[bin], 1u);
+    };
     // 16-byte loads over the aligned body, YS_UNROLL of them in flight per lane; the ragged ends one entry at a time
     const uint32_t a0 = (begin + PER - 1u) & ~(PER - 1u), a1 = end & ~(PER - 1u);
     if (a0 < a1) {
-        ys_add<NB>(h, (begin + tid < a0) ? bin_of(ent[begin + tid]) : NONE);
-        ys_add<NB>(h, (a1 + tid < end) ? bin_of(ent[a1 + tid]) : NONE);
+        if (begin + tid < a0) add1(bin_of(ent[begin + tid]));
+        if (a1 + tid < end) add1(bin_of(ent[a1 + tid]));
         const uint4 *ent4 = reinterpret_cast<const uint4 *>(ent);
         const uint32_t q1 = a1 / PER;
-        for (uint32_t qb = a0 / PER; qb < q1; qb += YS_NT * YS_UNROLL) {  // wave-uniform trip count
+        for (uint32_t qb = a0 / PER; qb < q1; qb += YS_NT * YS_UNROLL) {
             uint4 v[YS_UNROLL];
 #pragma unroll
             for (int u = 0; u < YS_UNROLL; ++u) {
@@ -900,21 +888,32 @@ __device__ __forceinline__ void ys_count_range(uint32_t *h, const ET *ent, uint3
             }
 #pragma unroll
             for (int u = 0; u < YS_UNROLL; ++u) {
-                const bool in = qb + u * YS_NT + tid < q1;
+                if (qb + u * YS_NT + tid >= q1) continue;
                 const uint32_t word[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                uint32_t run_bin = NONE, run_len = 0;
+                auto step = [&](uint32_t bin) {
+                    if (bin == run_bin) {
+                        ++run_len;
+                    } else {
+                        if (run_bin < NB) atomicAdd(&h[run_bin], run_len);
+                        run_bin = bin;
+                        run_len = 1;
+                    }
+                };
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if constexpr (sizeof(ET) == 2) {
-                        ys_add<NB>(h, in ? bin_of(word[c] & 0xFFFFu) : NONE);
-                        ys_add<NB>(h, in ? bin_of(word[c] >> 16) : NONE);
+                        step(bin_of(word[c] & 0xFFFFu));
+                        step(bin_of(word[c] >> 16));
                     } else {
-                        ys_add<NB>(h, in ? bin_of(word[c]) : NONE);
+                        step(bin_of(word[c]));
                     }
                 }
+                if (run_bin < NB) atomicAdd(&h[run_bin], run_len);
             }
         }
     } else {
-        for (uint32_t ib = begin; ib < end; ib += YS_NT) ys_add<NB>(h, (ib + tid < end) ? bin_of(ent[ib + tid]) : NONE);
+        for (uint32_t i = begin + tid; i < end; i += YS_NT) add1(bin_of(ent[i]));
     }
 }
 
