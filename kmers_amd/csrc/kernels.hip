@@ -1667,8 +1667,10 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         a.tile0 = t0;
         a.low_bits = low_bits;
         KK_CHECK(hipMemsetAsync(scal, 0, 64, s));  // [8] = length of the overflow queue
-        // a slice's workgroup counts at most `cap` entries itself: twice the mean range, at least two overflow chunks
-        uint64_t cap64 = 2 * ((uint64_t)nt * TILE / n_ranges);
+        // a slice's workgroup counts at most `cap` entries itself: a little over the mean range (the longest workgroup sets
+        // the kernel's time when there is one wave of them), at least two overflow chunks
+        uint64_t cap64 = (uint64_t)nt * TILE / n_ranges;
+        cap64 += cap64 / 4;  // 1.25 x the mean range (of positions: >= entries)
         if (cap64 < 2 * (uint64_t)YS_OVF_CHUNK) cap64 = 2 * (uint64_t)YS_OVF_CHUNK;
         if (const char *e = getenv("KMERS_Y_CAP")) cap64 = strtoull(e, nullptr, 10) ? strtoull(e, nullptr, 10) : 1;  // env: tests
         const uint32_t cap = (uint32_t)(cap64 > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap64);
