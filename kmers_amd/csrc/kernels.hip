@@ -551,13 +551,16 @@ __global__ __launch_bounds__(NT) void k_hist_entries(const ET *ent, const uint32
 //   YKEYS (y for K >= 9, narrow entries from the bases): sort key = id >> low_bits, payload = the low bits, no records.
 //   ORDER_FREE (the y path): the entries of a (digit, tile) may land in any order -- a histogram follows, not a
 //   run-length reduce -- so the rank is simply what one returning LDS atomic on the tile's digit counter hands out.
+//   Mode 1: every tile.  Mode 2 (second pass of the y path, whose output must stay ordered by the byte the first pass
+//   sorted on): only tiles that lie inside one region of the input, i.e. all but ~256 of them.
 //   OUT16 (y, one pass, K <= 12): only the low 16 bits of an entry mean anything (the sort key is the region):
 //   `out` is an array of uint16_t.
-template <bool FROM_BASES, class ET, bool YKEYS = false, bool ORDER_FREE = false, bool OUT16 = false>
+template <bool FROM_BASES, class ET, bool YKEYS = false, int ORDER_FREE = 0, bool OUT16 = false>
 __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, const uint32_t *p_count, int shift,
                                                    const uint32_t *tilebase, uint32_t n_tiles, ET *out, const uint32_t *regions) {
     constexpr bool NARROW = sizeof(ET) == 4;
-    static_assert(!YKEYS || (FROM_BASES && NARROW && ORDER_FREE), "y keys: from the bases, narrow entries, any order");
+    static_assert(!YKEYS || (FROM_BASES && NARROW && ORDER_FREE == 1), "y keys: from the bases, narrow entries, any order");
+    static_assert(ORDER_FREE != 2 || (!FROM_BASES && NARROW), "mode 2 is for the y path's second pass");
     static_assert(IPT == 16, "one packed word (16 windows) per thread and tile");
     static_assert(!ORDER_FREE || NARROW, "order-free partition is the y path's: narrow entries");
     // entry staging; its first NW*RADIX 8-byte words double as the match masks (below)
@@ -627,7 +630,13 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
     KK_STAMP_BEGIN();
     for (uint32_t tile = t0; tile < t1; ++tile) {
         const uint64_t base = (uint64_t)tile * TILE;
-        if (ORDER_FREE) {
+        bool of = ORDER_FREE == 1;  // workgroup-uniform
+        if constexpr (ORDER_FREE == 2) {
+            const uint32_t r = region_search(sreg, (uint32_t)base);
+            const uint64_t tile_last = (base + TILE < E) ? base + TILE : E;
+            of = sreg[r + 1] >= tile_last;
+        }
+        if (of) {
             if (tid < RADIX) wcnt[0][tid] = 0;
         } else {
             for (uint32_t i = tid; i < NW * RADIX; i += NT) {
@@ -693,11 +702,13 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
             // order, so the read sees all 64 ORs; OR is order-independent, so the ranks are deterministic.  The lowest
             // lane of each group advances the (wave, digit) counter and clears the word for the next round.
             // (An 8-ballot match in registers gives the same masks for ~45 more VALU instructions per round.)
-            if constexpr (ORDER_FREE) {
-                uint32_t r = 0;
-                if (ok) r = atomicAdd(&wcnt[0][d], 1u);
-                rank[j] = ok ? (r | (ab << 16)) : NONE;
-                continue;
+            if constexpr (ORDER_FREE != 0) {
+                if (of) {
+                    uint32_t r = 0;
+                    if (ok) r = atomicAdd(&wcnt[0][d], 1u);
+                    rank[j] = ok ? (r | (ab << 16)) : NONE;
+                    continue;
+                }
             }
             u64 m = 0;
             uint32_t before = 0;
@@ -724,7 +735,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
         uint32_t dtot = 0;
         uint32_t wc[NW];
         if (tid < RADIX) {
-            if (ORDER_FREE) {
+            if (of) {
                 dtot = wcnt[0][tid];
             } else {
 #pragma unroll
@@ -737,7 +748,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
         uint32_t tile_count;
         const uint32_t dstart = block_excl_scan(dtot, stmp, tile_count);
         if (tid < RADIX) {
-            if (ORDER_FREE) {
+            if (of) {
                 wcnt[0][tid] = dstart;
             } else {
 #pragma unroll
@@ -756,7 +767,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
                     d = FROM_BASES ? ((rank[j] >> 16) & 255u) : ((uint32_t)e[j] >> 24);
                 else
                     d = __builtin_amdgcn_ubfe(entry_key((u64)e[j]), (uint32_t)shift, 8u);
-                const uint32_t slot = (ORDER_FREE ? wcnt[0][d] : wrow[d]) + (rank[j] & 0xFFFFu);
+                const uint32_t slot = (of ? wcnt[0][d] : wrow[d]) + (rank[j] & 0xFFFFu);
                 sent[slot] = e[j];
                 if constexpr (NARROW) saux[slot] = (uint8_t)(rank[j] >> 16);
             }
@@ -1684,10 +1695,10 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         pt.mark("k_scan");
         hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, nt, c_E, regs0);
         if (two_pass)
-            hipLaunchKernelGGL((k_scatter<true, uint32_t, true, true, false>), pgrid, block, 0, s, a, (const uint32_t *)nullptr, c_E, 0,
+            hipLaunchKernelGGL((k_scatter<true, uint32_t, true, 1, false>), pgrid, block, 0, s, a, (const uint32_t *)nullptr, c_E, 0,
                                c_hist, nt, entA, (const uint32_t *)nullptr);
         else  // one pass: 2-byte payloads
-            hipLaunchKernelGGL((k_scatter<true, uint32_t, true, true, true>), pgrid, block, 0, s, a, (const uint32_t *)nullptr, c_E, 0,
+            hipLaunchKernelGGL((k_scatter<true, uint32_t, true, 1, true>), pgrid, block, 0, s, a, (const uint32_t *)nullptr, c_E, 0,
                                c_hist, nt, entA, (const uint32_t *)nullptr);
         pt.mark("k_scatter<bases,y>");
         const uint32_t *sorted = entA, *final_regions = regs0;
@@ -1697,8 +1708,8 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
             if (int rc = scan_tilehist(hist, nt, bsum, &scal[4], s)) return rc;
             pt.mark("k_scan");
             hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, nt, c_E, regs1);
-            // this pass stays stable: k_count_y_sorted searches a region by the byte pass 0 sorted on
-            hipLaunchKernelGGL((k_scatter<false, uint32_t>), pgrid, block, 0, s, a, (const uint32_t *)entA, c_E, 8, c_hist, nt, entB,
+            // this pass keeps the order of the byte pass 0 sorted on (k_count_y_sorted searches a region by it): mode 2
+            hipLaunchKernelGGL((k_scatter<false, uint32_t, false, 2>), pgrid, block, 0, s, a, (const uint32_t *)entA, c_E, 8, c_hist, nt, entB,
                                (const uint32_t *)regs0);
             pt.mark("k_scatter<entries>");
             sorted = entB;
