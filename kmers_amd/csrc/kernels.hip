@@ -819,26 +819,27 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
 //   entries: one pass   v = low bits                       sort key = region
 //            two passes v = (sort key & 255) << 24 | low   sort key = region << 8 | v >> 24
 
-// First index in [lo, hi) whose entry's top byte is >= c (hi if none); the range is sorted by that byte.
-// One wave, all 64 lanes; 64 probes per step.
-__device__ __forceinline__ uint32_t wave_lower_bound_byte(const uint32_t *ent, uint32_t lo, uint32_t hi, uint32_t c) {
-    const uint32_t lane = lane_id();
-    while (hi - lo > 64u) {
-        const uint32_t step = (hi - lo + 63u) / 64u;
-        const uint64_t p = (uint64_t)lo + (uint64_t)lane * step;
-        const bool ge = (p < hi) ? ((ent[p] >> 24) >= c) : true;
-        const u64 m = __ballot(ge);
-        const uint32_t f = m ? (uint32_t)__ffsll((long long)m) - 1u : 64u;  // first probe that is >= c
-        if (f == 0) return lo;
-        const uint64_t nhi = (uint64_t)lo + (uint64_t)f * step;  // f == 64: beyond hi
-        lo = lo + (f - 1u) * step + 1u;                           // probe f-1 is < c
-        if (nhi < hi) hi = (uint32_t)nhi;
+// Two passes: bounds[k] = index of the first entry whose 16-bit sort key (region << 8 | top byte) is >= k, for
+// k = 0 .. 65536 -- one thread and one binary search per key (inside a region the entries are ordered by that byte).
+// The slices' workgroups read their entry ranges from this table instead of searching (two dependent chains of global
+// loads per workgroup, ~8 us each, were most of a small slice's life).
+__global__ void k_bucket_bounds(const uint32_t *ent, const uint32_t *regions, uint32_t *bounds) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > 65536u) return;
+    if (k == 65536u) {
+        bounds[k] = regions[RADIX];
+        return;
     }
-    const uint32_t p = lo + lane;
-    const bool ge = (p < hi) ? ((ent[p] >> 24) >= c) : true;
-    const u64 m = __ballot(ge);
-    const uint32_t f = m ? (uint32_t)__ffsll((long long)m) - 1u : 64u;
-    return (lo + f < hi) ? lo + f : hi;
+    const uint32_t r = k >> 8, c = k & 255u;
+    uint32_t lo = regions[r], hi = regions[r + 1];
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((ent[mid] >> 24) >= c)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    bounds[k] = lo;
 }
 
 constexpr int YS_NT = 1024, YS_UNROLL = 4;
@@ -934,34 +935,19 @@ struct YOverflow {
 
 // One workgroup per slice.  A slice with more than `cap` entries (a hot bucket: poly-A) keeps its first `cap` and
 // queues the rest for k_count_y_overflow, which spreads it over many workgroups.
+// `regions`: one pass the 257 region starts; two passes the 65537 bucket bounds of k_bucket_bounds.
 template <int BPB_LOG2, class ET>
 __global__ __launch_bounds__(YS_NT) void k_count_y_sorted(const ET *ent, const uint32_t *regions, int two_pass, int low_bits,
                                                           int32_t *counts, uint32_t cap, uint32_t *ovf_count, YOverflow *ovf,
                                                           uint32_t ovf_cap) {
     constexpr uint32_t NB = 1u << BPB_LOG2;
-    __shared__ uint32_t h[NB];
+    __shared__ __attribute__((aligned(16))) uint32_t h[NB];
     __shared__ uint32_t s_range[2];
-    const uint32_t tid = threadIdx.x, w = tid >> 6;
+    const uint32_t tid = threadIdx.x;
     const YSlice y = ys_slice<BPB_LOG2>(blockIdx.x, two_pass, low_bits);
     for (uint32_t i = tid; i < NB; i += YS_NT) h[i] = 0;
-    if (!two_pass) {  // host guarantees nk == 1: the slice is (part of) region k_lo
-        if (tid < 2) s_range[tid] = regions[y.k_lo + tid];
-    } else {
-        const uint32_t r = y.k_lo >> 8;
-        const uint32_t rb = regions[r], re = regions[r + 1];
-        if constexpr (sizeof(ET) == 4) {  // (two passes always store 4-byte entries)
-            if (w == 0) {
-                const uint32_t b = wave_lower_bound_byte(ent, rb, re, y.c_lo);
-                if (lane_id() == 0) s_range[0] = b;
-            } else if (w == 1) {
-                const uint32_t c_hi = y.c_lo + y.nk;
-                const uint32_t e = (c_hi > 255u) ? re : wave_lower_bound_byte(ent, rb, re, c_hi);
-                if (lane_id() == 0) s_range[1] = e;
-            }
-        } else if (tid < 2) {
-            s_range[tid] = tid ? re : rb;
-        }
-    }
+    // one pass: the host guarantees nk == 1 (the slice is a region or half of one); two passes: nk buckets
+    if (tid < 2) s_range[tid] = regions[y.k_lo + (tid ? y.nk : 0u)];
     lds_sync();
     const uint32_t begin = s_range[0];
     uint32_t end = s_range[1];
@@ -979,9 +965,37 @@ __global__ __launch_bounds__(YS_NT) void k_count_y_sorted(const ET *ent, const u
     }
     ys_count_range<NB, ET>(h, ent, begin, end, y);
     lds_sync();
-    for (uint32_t i = tid; i < NB; i += YS_NT) {
-        const uint32_t c = h[i];
-        if (c) counts[y.bin0 + i] += (int32_t)c;  // this launch's only writer of these bins
+    // counts[slice] += h: this launch's only writer of these bins, so plain read-modify-writes -- four bins per lane
+    // and all of a thread's loads issued before its first store (one dependent load-add-store per bin kept a small
+    // slice's workgroup alive for ~50 us: 32 round trips)
+    int32_t *const dst = counts + y.bin0;
+    if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+        constexpr uint32_t G = NB / 4, PER_T = (G + YS_NT - 1) / YS_NT;
+        const uint4 *h4 = reinterpret_cast<const uint4 *>(h);
+        int4 *dst4 = reinterpret_cast<int4 *>(dst);
+        uint4 c[PER_T];
+        int4 v[PER_T];
+#pragma unroll
+        for (uint32_t u = 0; u < PER_T; ++u) {
+            const uint32_t g = tid + u * YS_NT;
+            c[u] = (g < G) ? h4[g] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < PER_T; ++u) {
+            const uint32_t g = tid + u * YS_NT;
+            v[u] = (c[u].x | c[u].y | c[u].z | c[u].w) ? dst4[g] : make_int4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < PER_T; ++u) {
+            const uint32_t g = tid + u * YS_NT;
+            if (c[u].x | c[u].y | c[u].z | c[u].w)
+                dst4[g] = make_int4(v[u].x + (int)c[u].x, v[u].y + (int)c[u].y, v[u].z + (int)c[u].z, v[u].w + (int)c[u].w);
+        }
+    } else {  // a caller's array that is not 16-byte aligned
+        for (uint32_t i = tid; i < NB; i += YS_NT) {
+            const uint32_t c = h[i];
+            if (c) dst[i] += (int32_t)c;
+        }
     }
 }
 
@@ -1557,7 +1571,7 @@ struct YLayout {
     uint64_t hist_len;
     uint32_t scan_blocks;
     int n_buf;
-    size_t off_entA, off_entB, off_hist, off_blocksums, off_scalars, off_regions, off_ovf, bytes;
+    size_t off_entA, off_entB, off_hist, off_blocksums, off_scalars, off_regions, off_ovf, off_bounds, bytes;
     int slice_log2;     // bins per workgroup of the final histogram kernel
     uint32_t slices;    // 4^K >> slice_log2: also the capacity of the overflow queue
 };
@@ -1587,6 +1601,7 @@ static YLayout y_layout_for(uint32_t chunk_tiles, int K) {
     l.off_scalars = take(64);
     l.off_regions = take(2 * (RADIX + 1) * 4);
     l.off_ovf = take((size_t)l.slices * sizeof(YOverflow));
+    l.off_bounds = take(l.n_buf == 2 ? (size_t)65537 * 4 : 0);
     l.bytes = o;
     return l;
 }
@@ -1713,7 +1728,9 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
                                (const uint32_t *)regs0);
             pt.mark("k_scatter<entries>");
             sorted = entB;
-            final_regions = regs1;
+            uint32_t *bounds = (uint32_t *)(ws + l.off_bounds);
+            hipLaunchKernelGGL(k_bucket_bounds, dim3(65537 / 256 + 1), dim3(256), 0, s, sorted, (const uint32_t *)regs1, bounds);
+            final_regions = bounds;
         }
         const uint16_t *sorted16 = (const uint16_t *)entA;
         switch (l.slice_log2) {  // one pass: 10, 12, 14 or 15 (2-byte entries); two passes: 15 (4-byte entries)

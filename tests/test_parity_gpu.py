@@ -85,7 +85,7 @@ def test_y_small_workspace_chunks(oracle, syn, K):
     ds = st.to_device()
     full = ds._lib.kmers_hip_y_workspace_bytes(st.n_pos, K)
     assert st.n_pos > 20 * 8192
-    for nbytes in (full, full // 7, 5 * 8192 * 8):          # one chunk, ~7 chunks, chunks of a few tiles
+    for nbytes in (full, full // 7, 800_000):                # one chunk, ~7 chunks, chunks of a few tiles
         ws = ds.y_workspace(K, nbytes)
         got = ds.count_y(K, workspace=ws)
         torch.cuda.synchronize()
