@@ -138,10 +138,18 @@ def main():
     from kmers_amd import _lib
     from kmers_amd.store import MODE_X, MODE_Y_FASTA, Store
 
+    # KMERS_BENCH_REHEARSAL=1: several ranks on ONE GPU over gloo (RCCL refuses two ranks on a device) -- to rehearse the
+    # multi-rank control flow on a one-GPU box; never a measurement
+    rehearsal = os.environ.get("KMERS_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     iso, reads = make_inputs(args, rank, want_reads=not kind_x)
     st = Store(iso if kind_x else reads, MODE_X if kind_x else MODE_Y_FASTA)
