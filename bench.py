@@ -76,7 +76,7 @@ def cpu_baseline(args, K, kind_x):
     cores = min(16, os.cpu_count() or 1)
     os.environ["KMER_NUM_THREADS"] = str(cores)
     if os.path.exists(ref_so):
-        lib, kind = kmtest.Lib(ref_so, ""), "reference"
+        lib, kind = kmtest.Lib(ref_so, "", hip=False), "reference"
     else:
         lib, kind, cores = kmtest.load_oracle(), "port", 1
     frac = 4 if kind_x else 10          # ~20-40 core-seconds of the reference either way

@@ -27,8 +27,8 @@ def cfiles(paths):
 class Lib:
     """Uniform view of a library exporting the six reference symbols under an optional prefix."""
 
-    def __init__(self, path, prefix=""):
-        if not prefix:
+    def __init__(self, path, prefix="", hip=True):
+        if not prefix and hip:                     # hip=False: a CPU library (the compiled reference)
             from kmers_amd import _lib
             _lib._share_hip_runtime_with_torch()   # one HIP runtime per process (see kmers_amd/_lib.py)
         self.lib = C.CDLL(path)
