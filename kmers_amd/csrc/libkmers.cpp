@@ -12,6 +12,7 @@
 #include "store.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -63,6 +64,74 @@ struct DevBuf {
     }
 };
 
+// KMERS_VERBOSE=2: wall time of the stages of a file-level call on stderr (the reference prints its phase times to
+// stdout, src/libkmers.cpp:34-41, :86-168; nothing is printed by default here)
+struct StageClock {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    StageClock() : on(false), t0(std::chrono::steady_clock::now()) {
+        const char *e = getenv("KMERS_VERBOSE");
+        on = e && atoi(e) >= 2;
+    }
+    void lap(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "libkmers: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
+// Device -> caller's (pageable) memory.  hipMemcpy into pageable memory goes through the runtime's small bounce
+// buffers at a fraction of the link rate; here 32 MiB chunks land in two pinned buffers by DMA while the host threads
+// move the previous chunk to its destination with `sink(dst offset, pinned src, bytes)` (a memcpy, or the "+=" of the
+// y calls).  Leaves the stream idle.
+template <class Sink>
+int d2h_chunks(const void *d_src, size_t bytes, hipStream_t s, const Sink &sink) {
+    if (bytes == 0) return KMERS_OK;
+    const size_t chunk = (size_t)32 << 20;
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int rc = KMERS_OK;
+    for (int i = 0; i < 2 && rc == KMERS_OK; ++i) {
+        if (hipHostMalloc(&pin[i], std::min(chunk, bytes), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess)
+            rc = KMERS_ERR_HIP;
+    }
+    const size_t n_chunks = (bytes + chunk - 1) / chunk;
+    auto issue = [&](size_t c) {
+        const size_t off = c * chunk, n = std::min(chunk, bytes - off);
+        if (hipMemcpyAsync(pin[c & 1], (const char *)d_src + off, n, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipEventRecord(ev[c & 1], s) != hipSuccess)
+            rc = KMERS_ERR_HIP;
+    };
+    if (rc == KMERS_OK) issue(0);
+    for (size_t c = 0; c < n_chunks && rc == KMERS_OK; ++c) {
+        if (hipEventSynchronize(ev[c & 1]) != hipSuccess) {
+            rc = KMERS_ERR_HIP;
+            break;
+        }
+        if (c + 1 < n_chunks) issue(c + 1);  // the next chunk's DMA runs under this chunk's host copy
+        const size_t off = c * chunk, n = std::min(chunk, bytes - off);
+        sink(off, (const char *)pin[c & 1], n);
+    }
+    if (rc != KMERS_OK) {
+        (void)hipGetLastError();
+        fprintf(stderr, "libkmers: HIP error in the device-to-host copy\n");
+    }
+    (void)hipStreamSynchronize(s);
+    for (int i = 0; i < 2; ++i) {
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+        if (pin[i]) (void)hipHostFree(pin[i]);
+    }
+    return rc;
+}
+
+int d2h_copy(void *dst, const void *d_src, size_t bytes, hipStream_t s) {
+    return d2h_chunks(d_src, bytes, s, [&](size_t off, const char *src, size_t n) {
+        kmers::parallel_for(n, (size_t)1 << 20, [&](size_t lo, size_t hi) { memcpy((char *)dst + off + lo, src + lo, hi - lo); });
+    });
+}
+
 int select_device() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
@@ -94,8 +163,10 @@ struct DevStore {
 
 int count_files(int n_files, const char *fnames[], int K, int *counts, int mode) {
     if (K < 1 || K > 16 || !counts || n_files < 0) return KMERS_ERR_BAD_ARG;
+    StageClock clk;
     StoreGuard g;
     if (int rc = kmers_store_ingest(n_files, fnames, mode, 0, 0, 1, &g.s)) return rc;
+    clk.lap("host ingest");
     if (int rc = select_device()) return rc;
     const kmers_store *st = g.s;
     const uint64_t n_pos = kmers_store_n_pos(st);
@@ -110,18 +181,21 @@ int count_files(int n_files, const char *fnames[], int K, int *counts, int mode)
     DevBuf d_ws;
     const size_t ws_bytes = kk::y_workspace_bytes(n_pos, K);
     if (ws_bytes) API_HIP(d_ws.alloc(ws_bytes));
+    clk.lap("H2D + device buffers");
     if (int rc = kk::count_y(ds.bases.as<uint32_t>(), st->bases_words, ds.valid.as<uint32_t>(), st->valid_words, n_pos, K,
                              dc.as<int32_t>(), d_ws.p, ws_bytes, s))
         return rc;
+    clk.lap("histogram (GPU, enqueue)");
     // the reference only ever increments the caller's array (src/libkmers.cpp:213-216): add, do not overwrite
-    std::unique_ptr<int32_t[]> h(new (std::nothrow) int32_t[M]);
-    if (!h) return KMERS_ERR_NOMEM;
-    API_HIP(hipMemcpyAsync(h.get(), dc.p, M * 4, hipMemcpyDeviceToHost, s));
-    API_HIP(hipStreamSynchronize(s));
-    const int32_t *src = h.get();
-    kmers::parallel_for((size_t)M, 1u << 20, [&](size_t lo, size_t hi) {
-        for (size_t i = lo; i < hi; ++i) counts[i] += src[i];
-    });
+    if (int rc = d2h_chunks(dc.p, M * 4, s, [&](size_t off, const char *src, size_t n) {
+            int *dst = counts + off / 4;
+            const int32_t *v = (const int32_t *)src;
+            kmers::parallel_for(n / 4, (size_t)1 << 18, [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; ++i) dst[i] += v[i];
+            });
+        }))
+        return rc;
+    clk.lap("counts += (D2H)");
     return KMERS_OK;
 }
 
@@ -129,8 +203,10 @@ int build_files(int n_files, const char *fnames[], int K, int L, int mode, float
                 uint64_t max_size, uint64_t *nnz, int *n_cols) {
     if (K < 1 || K > 16 || !row_ind || !nnz || !n_cols || n_files < 0 || (max_size && (!data || !col_ind)))
         return KMERS_ERR_BAD_ARG;
+    StageClock clk;
     StoreGuard g;
     if (int rc = kmers_store_ingest(n_files, fnames, mode, L, 0, 1, &g.s)) return rc;
+    clk.lap("host ingest");
     if (int rc = select_device()) return rc;
     const kmers_store *st = g.s;
     const uint64_t n_pos = kmers_store_n_pos(st), n_rec = kmers_store_n_rec(st);
@@ -147,6 +223,7 @@ int build_files(int n_files, const char *fnames[], int K, int L, int mode, float
     API_HIP(d_col.alloc(cap * 8));
     API_HIP(d_row.alloc((M + 1) * 8));
     API_HIP(d_ws.alloc(ws_bytes));
+    clk.lap("H2D + device buffers");
     uint64_t nz = 0;
     const int rc = kk::build_x(ds.bases.as<uint32_t>(), st->bases_words, ds.valid.as<uint32_t>(), st->valid_words,
                                ds.rec_start.as<uint64_t>(), n_pos, n_rec, 0, K, d_data.as<float>(), d_col.as<uint64_t>(),
@@ -157,12 +234,13 @@ int build_files(int n_files, const char *fnames[], int K, int L, int mode, float
         return KMERS_ERR_HIP;
     }
     if (rc) return rc;
-    API_HIP(hipMemcpyAsync(row_ind, d_row.p, (M + 1) * 8, hipMemcpyDeviceToHost, s));
+    clk.lap("build X (GPU)");
+    if (int e = d2h_copy(row_ind, d_row.p, (M + 1) * 8, s)) return e;
     if (nz) {
-        API_HIP(hipMemcpyAsync(col_ind, d_col.p, nz * 8, hipMemcpyDeviceToHost, s));
-        API_HIP(hipMemcpyAsync(data, d_data.p, nz * 4, hipMemcpyDeviceToHost, s));
+        if (int e = d2h_copy(col_ind, d_col.p, nz * 8, s)) return e;
+        if (int e = d2h_copy(data, d_data.p, nz * 4, s)) return e;
     }
-    API_HIP(hipStreamSynchronize(s));
+    clk.lap("D2H into the caller's arrays");
     *nnz = nz;
     *n_cols = (int)kmers_store_n_rec_total(st);
     return KMERS_OK;
