@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -146,6 +147,66 @@ struct Piece {
     bool lines;          // true: walk FASTA lines, false: raw bytes
 };
 
+// A growing array of trivially copyable T without value-initialisation (10^7 read records make std::vector's
+// zero-fill and push_back a serial stage of their own).
+template <class T>
+struct RawVec {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    RawVec() = default;
+    RawVec(const RawVec &) = delete;
+    RawVec &operator=(const RawVec &) = delete;
+    ~RawVec() { free(p); }
+    T *grow(size_t more) {  // room for `more` new elements at the end; returns the first of them (nullptr: no memory)
+        if (n + more > cap) {
+            size_t nc = std::max(n + more, cap + cap / 2 + 16);
+            T *q = (T *)realloc(p, nc * sizeof(T));
+            if (!q) return nullptr;
+            p = q;
+            cap = nc;
+        }
+        T *r = p + n;
+        n += more;
+        return r;
+    }
+    void push(const T &v) {
+        T *r = grow(1);
+        if (r) *r = v;
+    }
+    size_t size() const { return n; }
+    const T *begin() const { return p; }
+    const T *end() const { return p + n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+};
+
+// Exclusive prefix sums of f(0..n) in parallel: out[i] = sum_{j<i} f(j), returns the total.  out has n entries.
+template <class F>
+uint64_t parallel_prefix(size_t n, uint64_t *out, const F &f) {
+    if (n == 0) return 0;
+    const size_t grain = (size_t)1 << 16;
+    const size_t nc = (n + grain - 1) / grain;
+    std::vector<uint64_t> part(nc + 1, 0);
+    kmers::parallel_for(nc, 1, [&](size_t lo, size_t hi) {
+        for (size_t c = lo; c < hi; ++c) {
+            uint64_t a = 0;
+            for (size_t i = c * grain, e = std::min(n, i + grain); i < e; ++i) a += f(i);
+            part[c + 1] = a;
+        }
+    });
+    for (size_t c = 0; c < nc; ++c) part[c + 1] += part[c];
+    kmers::parallel_for(nc, 1, [&](size_t lo, size_t hi) {
+        for (size_t c = lo; c < hi; ++c) {
+            uint64_t a = part[c];
+            for (size_t i = c * grain, e = std::min(n, i + grain); i < e; ++i) {
+                out[i] = a;
+                a += f(i);
+            }
+        }
+    });
+    return part[nc];
+}
+
 inline const uint8_t *find_nl(const uint8_t *p, const uint8_t *end) {
     const void *r = memchr(p, '\n', (size_t)(end - p));
     return r ? (const uint8_t *)r : end;
@@ -177,12 +238,19 @@ void find_headers(const FileView &f, std::vector<size_t> &hdrs) {
             }
         }
     });
-    hdrs.push_back(0);
-    for (auto &v : part) hdrs.insert(hdrs.end(), v.begin(), v.end());
+    std::vector<size_t> at(n_chunks + 1, 1);  // slot 0 is offset 0
+    for (size_t c = 0; c < n_chunks; ++c) at[c + 1] = at[c] + part[c].size();
+    hdrs.resize(at[n_chunks]);
+    hdrs[0] = 0;
+    parallel_for(n_chunks, 1, [&](size_t lo, size_t hi) {
+        for (size_t c = lo; c < hi; ++c)
+            if (!part[c].empty()) memcpy(&hdrs[at[c]], part[c].data(), part[c].size() * sizeof(size_t));
+    });
 }
 
-void analyse_records(const FileView &f, const std::vector<size_t> &hdrs, bool want_nul, std::vector<RecInfo> &recs) {
-    recs.resize(hdrs.size());
+bool analyse_records(const FileView &f, const std::vector<size_t> &hdrs, bool want_nul, RawVec<RecInfo> &recs) {
+    recs.n = 0;
+    if (hdrs.size() && !recs.grow(hdrs.size())) return false;
     parallel_for(hdrs.size(), 256, [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
             const uint8_t *h = f.p + hdrs[i];
@@ -209,6 +277,7 @@ void analyse_records(const FileView &f, const std::vector<size_t> &hdrs, bool wa
             recs[i] = r;
         }
     });
+    return true;
 }
 
 // ---- streaming packer: appends bases at consecutive positions of the store arrays.
@@ -223,7 +292,43 @@ class StreamPacker {
     void push(const uint8_t *s, size_t n) {
         uint64_t pos = pos_;
         uint32_t bw = bw_, vw = vw_;
-        for (size_t i = 0; i < n; ++i) {
+        size_t i = 0;
+        // up to a word boundary one base at a time, then whole 16-base words without the per-base boundary tests
+        for (; i < n && (pos & 15); ++i) {
+            const uint32_t c = g_codes.t[s[i]];
+            bw |= (c & 3u) << (30 - 2 * (pos & 15));
+            vw |= (uint32_t)(c < 4) << (pos & 31);
+            ++pos;
+            if ((pos & 15) == 0) {
+                store(B + (pos - 1) / 16, bw, b_shared_);
+                b_shared_ = false;
+                bw = 0;
+            }
+            if ((pos & 31) == 0) {
+                store(V + (pos - 1) / 32, vw, v_shared_);
+                v_shared_ = false;
+                vw = 0;
+            }
+        }
+        for (; n - i >= 16 && (pos & 15) == 0; i += 16) {
+            uint32_t w = 0, m = 0;
+#pragma GCC unroll 16
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t c = g_codes.t[s[i + k]];
+                w |= (c & 3u) << (30 - 2 * k);
+                m |= (uint32_t)(c < 4) << k;
+            }
+            store(B + pos / 16, w, b_shared_);
+            b_shared_ = false;
+            vw |= m << (pos & 31);
+            pos += 16;
+            if ((pos & 31) == 0) {
+                store(V + (pos - 1) / 32, vw, v_shared_);
+                v_shared_ = false;
+                vw = 0;
+            }
+        }
+        for (; i < n; ++i) {
             const uint32_t c = g_codes.t[s[i]];
             const uint32_t ok = c < 4;
             bw |= (c & 3u) << (30 - 2 * (pos & 15));
@@ -379,6 +484,20 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
         shard < 0 || shard >= n_shards)
         return KMERS_ERR_BAD_ARG;
 
+    struct Lap {  // KMERS_VERBOSE=2: stage times on stderr
+        bool on;
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        Lap() {
+            const char *e = getenv("KMERS_VERBOSE");
+            on = e && atoi(e) >= 2;
+        }
+        void operator()(const char *what) {
+            if (!on) return;
+            const auto t1 = std::chrono::steady_clock::now();
+            fprintf(stderr, "libkmers:   ingest %-20s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+            t0 = t1;
+        }
+    } lap;
     const bool fastq = (mode == KMERS_MODE_Y_FASTQ);
     const bool cat = (mode == KMERS_MODE_X_CAT);
     const bool xmode = (mode == KMERS_MODE_X || cat);
@@ -387,33 +506,35 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
     // Everything that must outlive parsing: the mapped files and the inflated FASTQ sequences.
     std::vector<std::unique_ptr<FileView>> files((size_t)n_files);
     std::vector<std::vector<uint8_t>> fq((size_t)(fastq ? n_files : 0));
-    std::vector<uint64_t> rec_len;  // global (pre-shard) record lengths
-    std::vector<Piece> pieces;      // in global record order
+    RawVec<uint64_t> rec_len;  // global (pre-shard) record lengths
+    RawVec<Piece> pieces;      // in global record order (records without bases have no piece, or one that takes 0)
 
     if (fastq) {
         parallel_for((size_t)n_files, 1, [&](size_t lo, size_t hi) {
             for (size_t f = lo; f < hi; ++f) read_fastq_sequence(fnames[f], fq[f]);
         });
         for (int f = 0; f < n_files; ++f) {
-            pieces.push_back(Piece{fq[f].data(), fq[f].data() + fq[f].size(), (uint64_t)f, 0, fq[f].size(), false});
-            rec_len.push_back(fq[f].size());
+            pieces.push(Piece{fq[f].data(), fq[f].data() + fq[f].size(), (uint64_t)f, 0, fq[f].size(), false});
+            rec_len.push(fq[f].size());
         }
     } else {
         std::vector<size_t> hdrs;
-        std::vector<RecInfo> recs;
+        RawVec<RecInfo> recs;
         for (int f = 0; f < n_files; ++f) {
             files[f].reset(new FileView());
             FileView &fv = *files[f];
             if (!fv.open(fnames[f])) {
                 if (cat) {  // reference src/libkmers.cpp:402-403: the job just returns, the column stays empty
-                    rec_len.push_back(0);
+                    rec_len.push(0);
                     continue;
                 }
                 return KMERS_ERR_OPEN;  // reference src/libkmers.cpp:356-357, 440-441
             }
             if (getenv("KMERS_VERBOSE")) printf("processing %s\n", fnames[f]);
             find_headers(fv, hdrs);
-            analyse_records(fv, hdrs, xmode, recs);
+            lap("find headers");
+            if (!analyse_records(fv, hdrs, xmode, recs)) return KMERS_ERR_NOMEM;
+            lap("analyse records");
             if (cat) {
                 uint64_t full = 0, nul = UINT64_MAX;
                 for (const RecInfo &r : recs) {
@@ -427,27 +548,46 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
                 for (const RecInfo &r : recs) {
                     if (r.predicted || off >= eff) continue;
                     const uint64_t take = std::min<uint64_t>(r.full_len, eff - off);
-                    if (take) pieces.push_back(Piece{fv.p + r.seq_off, fv.p + r.end_off, rec, off, take, true});
+                    if (take) pieces.push(Piece{fv.p + r.seq_off, fv.p + r.end_off, rec, off, take, true});
                     off += r.full_len;
                 }
-                rec_len.push_back(eff);
+                rec_len.push(eff);
             } else {
-                for (const RecInfo &r : recs) {
-                    if (r.predicted) continue;
-                    if (xmode && (l_skips_all || r.full_len < (uint64_t)L)) continue;
-                    const uint64_t len = xmode ? std::min(r.full_len, r.nul_at) : r.full_len;
-                    const uint64_t rec = rec_len.size();
-                    if (len) pieces.push_back(Piece{fv.p + r.seq_off, fv.p + r.end_off, rec, 0, len, true});
-                    rec_len.push_back(len);
-                }
+                // kept records get consecutive numbers: count, prefix, fill -- all in parallel
+                auto kept = [&](size_t i) -> uint64_t {
+                    const RecInfo &r = recs[i];
+                    if (r.predicted) return 0;
+                    if (xmode && (l_skips_all || r.full_len < (uint64_t)L)) return 0;
+                    return 1;
+                };
+                std::unique_ptr<uint64_t[]> slot(new (std::nothrow) uint64_t[recs.size() + 1]);
+                if (!slot) return KMERS_ERR_NOMEM;
+                const uint64_t n_kept = parallel_prefix(recs.size(), slot.get(), kept);
+                const uint64_t rec0 = rec_len.size();
+                uint64_t *rl = rec_len.grow((size_t)n_kept);
+                Piece *pc = pieces.grow((size_t)n_kept);
+                if (n_kept && (!rl || !pc)) return KMERS_ERR_NOMEM;
+                parallel_for(recs.size(), (size_t)1 << 14, [&](size_t lo, size_t hi) {
+                    for (size_t i = lo; i < hi; ++i) {
+                        if (!kept(i)) continue;
+                        const RecInfo &r = recs[i];
+                        const uint64_t len = xmode ? std::min(r.full_len, r.nul_at) : r.full_len;
+                        const uint64_t k = slot[i];
+                        rl[k] = len;
+                        pc[k] = Piece{fv.p + r.seq_off, fv.p + r.end_off, rec0 + k, 0, len, true};
+                    }
+                });
             }
         }
     }
 
+    lap("pieces");
     // ---- shard selection: contiguous record ranges with about equal numbers of positions
     const uint64_t n_total = rec_len.size();
-    uint64_t pos_total = 0;
-    for (uint64_t l : rec_len) pos_total += l + 1;
+    std::unique_ptr<uint64_t[]> gstart(new (std::nothrow) uint64_t[n_total + 1]);  // global start position of every record
+    if (!gstart) return KMERS_ERR_NOMEM;
+    const uint64_t pos_total = parallel_prefix((size_t)n_total, gstart.get(), [&](size_t r) { return rec_len[r] + 1; });
+    gstart[n_total] = pos_total;
     uint64_t r_lo = 0, r_hi = n_total;
     if (n_shards > 1) {
         // record r belongs to shard floor(start_pos(r) * n_shards / pos_total)
@@ -455,12 +595,16 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
             if (s <= 0) return 0;
             if (s >= n_shards) return n_total;
             const long double target = (long double)pos_total * s / n_shards;
-            uint64_t acc = 0, r = 0;
-            for (; r < n_total; ++r) {
-                if ((long double)acc >= target) break;
-                acc += rec_len[r] + 1;
+            // first record whose start position is >= target
+            uint64_t lo = 0, hi = n_total;
+            while (lo < hi) {
+                const uint64_t mid = lo + (hi - lo) / 2;
+                if ((long double)gstart[mid] >= target)
+                    hi = mid;
+                else
+                    lo = mid + 1;
             }
-            return r;
+            return lo;
         };
         r_lo = bound(shard);
         r_hi = bound(shard + 1);
@@ -471,13 +615,14 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
     st->n_rec_total = n_total;
     st->first_rec = r_lo;
     st->rec_start.resize((size_t)(r_hi - r_lo) + 1);
-    uint64_t acc = 0;
-    for (uint64_t r = r_lo; r < r_hi; ++r) {
-        st->rec_start[(size_t)(r - r_lo)] = acc;
-        acc += rec_len[r] + 1;
+    {
+        const uint64_t base = gstart[r_lo];
+        uint64_t *rs = st->rec_start.data();
+        parallel_for((size_t)(r_hi - r_lo) + 1, (size_t)1 << 16, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) rs[i] = gstart[r_lo + i] - base;
+        });
     }
-    st->rec_start[(size_t)(r_hi - r_lo)] = acc;
-    const uint64_t n_pos = acc;
+    const uint64_t n_pos = st->rec_start.back();
     st->bases_words = (size_t)((n_pos + 15) / 16) + 4;
     st->valid_words = (size_t)((n_pos + 31) / 32) + 4;
     bool pin_b = false, pin_v = false;
@@ -490,6 +635,7 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
         return KMERS_ERR_NOMEM;
     }
     st->pinned = pin_b;
+    lap("record table + alloc");
 
     // zero + pack, in parallel
     {
@@ -497,13 +643,12 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
         parallel_for(st->bases_words, zg, [&](size_t lo, size_t hi) { memset(st->bases + lo, 0, (hi - lo) * 4); });
         parallel_for(st->valid_words, zg, [&](size_t lo, size_t hi) { memset(st->valid + lo, 0, (hi - lo) * 4); });
     }
+    lap("zero");
     // pieces of this shard: records are ascending in `pieces`, find the range by binary search
-    auto plo = std::lower_bound(pieces.begin(), pieces.end(), r_lo,
-                                [](const Piece &p, uint64_t r) { return p.rec < r; });
-    auto phi = std::lower_bound(pieces.begin(), pieces.end(), r_hi,
-                                [](const Piece &p, uint64_t r) { return p.rec < r; });
+    const Piece *plo = std::lower_bound(pieces.p, pieces.p + pieces.n, r_lo, [](const Piece &p, uint64_t r) { return p.rec < r; });
+    const Piece *phi = std::lower_bound(pieces.p, pieces.p + pieces.n, r_hi, [](const Piece &p, uint64_t r) { return p.rec < r; });
     const size_t np = (size_t)(phi - plo);
-    const Piece *pp = np ? &*plo : nullptr;
+    const Piece *pp = np ? plo : nullptr;
     // grain: aim at ~1 MiB of bases per chunk for typical transcript lengths, 1 piece minimum
     size_t grain = 1;
     if (np) {
@@ -517,6 +662,7 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
         }
     });
 
+    lap("pack");
     *out = st.release();
     return KMERS_OK;
 }
