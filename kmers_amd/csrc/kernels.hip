@@ -1,29 +1,34 @@
 // kernels.hip -- hand-written gfx950 (MI355X, CDNA4) kernels for the k-mer shredding / counting hot path.
 //
 // What they replace in the reference (src/libkmers.cpp):
-//   valid_kmer + kmer_to_id per window (:222-227, :321-326, :331-345)  -> window_at(): one 64-bit bit-field
+//   valid_kmer + kmer_to_id per window (:222-227, :321-326, :331-345)  -> window_at() / word_window(): a bit-field
 //                                                                         extract from the 2-bit packed store
-//   count_kmers, atomic ++ into a shared int array (:213-216, :320-328) -> k_count_y*
+//   count_kmers, atomic ++ into a shared int array (:213-216, :320-328)
+//        -> y, K <= 8: k_count_y_lds (LDS tables, windows shifted out of registers);
+//           y, K >= 9: partition by the top 8 / 16 id bits (k_hist_words_y, k_scatter<..YKEYS..>, for K >= 13 also
+//           k_hist_entries, k_scatter mode 2, k_bucket_bounds), then per-slice LDS tables (k_count_y_sorted,
+//           k_count_y_overflow); k_count_y_global is the plain-atomics kernel kept for A-B runs.
 //   collect_kmers (unordered_map per isoform) + fill_indices_coo (:218-238)
 //   + ThreadPoolLocalData::to_csr (sort by row, gather, sort by col, :77-169)
 //        -> "shred, stable radix partition by k-mer id, run-length reduce":
 //           k_hist_bases / k_scatter<true> (pass 0, straight from the packed bases), k_hist_entries /
-//           k_scatter<false> (further 8-bit digits), k_rle (one CSR entry per run of equal (k-mer, column),
-//           value float(run length) / float(valid windows of the column), row pointer by gap filling).
+//           k_scatter<false> (further 8-bit digits), k_cscan_* (tile histogram -> positions), k_rle (one CSR entry per
+//           run of equal (k-mer, column), value float(run length) / float(valid windows of the column), row pointer
+//           by gap filling), k_fill_tasks.
 //
-// Why a sort and not a hash: every window instance becomes an 8-byte (k-mer id, column) entry in position
-// order, i.e. column-ascending.  A STABLE least-significant-digit partition by k-mer id therefore leaves,
-// inside every row, the columns ascending and the instances of one (row, column) adjacent -- exactly the CSR
-// order the reference produces, with no per-isoform hash table, no long-isoform special case and a memory
-// access pattern that is fully coalesced (HBM-bound, no MFMA: nothing here is a contraction).
+// Why a sort and not a hash: every window instance becomes a (k-mer id, column) entry in position order, i.e.
+// column-ascending.  A STABLE least-significant-digit partition by k-mer id therefore leaves, inside every row, the
+// columns ascending and the instances of one (row, column) adjacent -- exactly the CSR order the reference produces,
+// with no per-isoform hash table, no long-isoform special case and coalesced traffic (HBM-bound, no MFMA: nothing
+// here is a contraction).  Entries are 8 bytes (id << 32 | column), or 4 bytes for K <= 8 (see "narrow entries").
 //
 // Geometry: 512-thread workgroups (8 wave64), a tile is 8192 entries.  Wave w of a tile owns the contiguous
 // chunk [w*1024, (w+1)*1024) and walks it in 16 rounds of 64 consecutive entries, so the order
-// (wave, round, lane) is the entry order; ranks inside a digit come from a wave-wide ballot match, which is
-// deterministic (no atomics decide an order anywhere).  The partition kernels are persistent: a workgroup walks
-// a contiguous range of tiles and fetches tile t+1 (into registers) while tile t is ranked and written, so HBM
-// latency is paid once per workgroup, not once per tile, and neighbouring output segments of one digit are
-// written by the same CU close in time (they merge in that XCD's L2).
+// (wave, round, lane) is the entry order; ranks inside a digit come from a wave-wide match (an LDS OR-mask per
+// (wave, digit)), which is deterministic (no atomic decides an order on the X path).  The partition kernels are
+// persistent: a workgroup walks a contiguous range of tiles and fetches tile t+1 (into registers) while tile t is
+// ranked and written, so HBM latency is paid once per workgroup, not once per tile.  The y path needs no order at
+// all (a histogram follows), so there ranks are what a returning LDS atomic hands out.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
