@@ -135,6 +135,8 @@ __global__ void k_regions(const uint32_t *tilebase, uint32_t n_tiles, const uint
 __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Exclusive scan over the NT threads' values (thread order); total gets the sum.  All threads call it.
+// PRE_SYNCED: the caller has a workgroup barrier between the last read of stmp and this call (saves one here).
+template <bool PRE_SYNCED = false>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *stmp /* NW */, uint32_t &total) {
     const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
     uint32_t inc = v;
@@ -143,7 +145,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *stmp /
         const uint32_t t = __shfl_up(inc, d);
         if (lane >= (uint32_t)d) inc += t;
     }
-    lds_sync();  // stmp may still be read from a previous call
+    if (!PRE_SYNCED) lds_sync();  // stmp may still be read from a previous call
     if (lane == 63) stmp[w] = inc;
     lds_sync();
     uint32_t base = 0, tot = 0;
@@ -222,7 +224,8 @@ __device__ __forceinline__ void tile_commit(TileLds &L, const TilePf &p, uint32_
         const uint32_t pc = (tid < TILE / 32) ? (uint32_t)__popc(p.f) : 0u;
         const uint32_t pair = pc + __shfl_xor(pc, 1);
         uint32_t tot;
-        const uint32_t ex = block_excl_scan((tid & 1) ? 0u : pair, stmp, tot);  // ends after a barrier
+        // every caller has at least one barrier between a tile's last use of stmp and the next tile's commit
+        const uint32_t ex = block_excl_scan<true>((tid & 1) ? 0u : pair, stmp, tot);
         if (tid < TILE / 32 && !(tid & 1)) L.spre[tid >> 1] = ex;
     }
     lds_sync();
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
             }
         }
         uint32_t tile_count;
-        const uint32_t dstart = block_excl_scan(dtot, stmp, tile_count);
+        const uint32_t dstart = block_excl_scan<true>(dtot, stmp, tile_count);  // (the barrier after the ranking)
         if (tid < RADIX) {
             if (of) {
                 wcnt[0][tid] = dstart;
