@@ -132,3 +132,41 @@ def test_no_gpu_fails_loudly(product):
     from kmers_amd import transcriptome_reader as tr
     with pytest.raises(RuntimeError, match="no usable HIP device"):
         tr.transcriptome_to_x(1, p[0])
+
+
+@pytest.mark.parametrize("mode", [MODE_X, MODE_Y_FASTA])
+def test_many_small_records(tmp_path, mode):
+    """3e5 tiny records (several of the ingest's 65,536-record numbering chunks, two files): numbering, filters,
+    lengths and the packed bases against a plain Python parse, whole and in shards."""
+    rng = np.random.default_rng(77)
+    want = []                                             # kept records, in file order
+    L = 6
+    paths = []
+    for fi, n in enumerate((200_000, 100_000)):
+        p = str(tmp_path / f"m{fi}.fsa")
+        paths.append(p)
+        lens = rng.integers(0, 40, n)
+        pred = rng.random(n) < 0.02
+        bases = np.frombuffer(b"ACGTN", np.uint8)[rng.choice(5, int(lens.sum()), p=[.24, .24, .24, .24, .04])]
+        off = np.concatenate([[0], np.cumsum(lens)])
+        with open(p, "wb") as f:
+            chunks = []
+            for i in range(n):
+                s = bases[off[i]:off[i + 1]].tobytes()
+                chunks.append(b">r%d%s\n%s\n" % (i, b" PREDICTED" if pred[i] else b"", s))
+                if pred[i] or (mode == MODE_X and len(s) < L):
+                    continue
+                want.append(s)
+            f.write(b"".join(chunks))
+    st = Store(paths, mode, L=L)
+    assert st.n_rec == len(want) and st.n_rec_total == len(want)
+    got = st.sequences()
+    assert got == want
+    # three shards: contiguous, complete, same records
+    merged, first = [], 0
+    for s in range(3):
+        sh = Store(paths, mode, L=L, shard=s, n_shards=3)
+        assert sh.first_rec == first and sh.n_rec_total == len(want)
+        merged += sh.sequences()
+        first += sh.n_rec
+    assert merged == want
