@@ -51,6 +51,7 @@ constexpr int WCHUNK = 64 * IPT; // entries per wave (1024)
 #ifndef RLE_IPT_WIDE
 #define RLE_IPT_WIDE 16
 #endif
+static_assert(RLE_IPT_NARROW >= IPT && RLE_IPT_WIDE >= IPT, "the chained-scan status array holds one word per 8192-entry tile");
 constexpr int RADIX = 256;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int FILL_INLINE = 32;          // row-pointer gaps up to this many rows are filled by the finding lane
