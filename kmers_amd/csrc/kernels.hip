@@ -46,12 +46,16 @@ constexpr int IPT = 16;          // rounds per wave
 constexpr int TILE = NT * IPT;   // entries per tile (8192)
 constexpr int WCHUNK = 64 * IPT; // entries per wave (1024)
 #ifndef RLE_IPT_NARROW
-#define RLE_IPT_NARROW 24
+#define RLE_IPT_NARROW 24   // k_rle: rounds per wave with 4-byte / 8-byte entries, threads per workgroup
 #endif
 #ifndef RLE_IPT_WIDE
 #define RLE_IPT_WIDE 16
 #endif
-static_assert(RLE_IPT_NARROW >= IPT && RLE_IPT_WIDE >= IPT, "the chained-scan status array holds one word per 8192-entry tile");
+#ifndef RLE_NT
+#define RLE_NT 1024
+#endif
+static_assert(RLE_NT * RLE_IPT_NARROW >= NT * IPT && RLE_NT * RLE_IPT_WIDE >= NT * IPT,
+              "the chained-scan status array holds one word per 8192-entry tile");
 constexpr int RADIX = 256;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int FILL_INLINE = 32;          // row-pointer gaps up to this many rows are filled by the finding lane
@@ -1204,18 +1208,20 @@ __device__ __forceinline__ u64 lookback_exclusive(u64 *status, uint32_t tile, u6
 //   scal[0] = E (instances, input), scal[1] = nnz (output), scal[2] = ntasks, scal[3] = err, scal[5] = ticket
 // Narrow entries are widened to the 8-byte form (k-mer id << 32 | column) as they are loaded (the id's upper part is
 // the region the entry sits in), so everything after the loads is common to both forms.
-// RIPT rounds per wave: a tile of this kernel is NT * RIPT entries (larger than the partition's: every tile pays one
-// chained-scan hand-off, ~5 us of mostly idle workgroup, so fewer and larger tiles win).
-template <class ET, int RIPT>
-__global__ __launch_bounds__(NT, 4) void k_rle(const ET *ent, uint32_t *scal, u64 *status, const uint32_t *rec_total,
+// RNT threads, RIPT rounds per wave: a tile of this kernel is RNT * RIPT entries, larger than the partition's: every
+// tile pays one chained-scan hand-off, so fewer and larger tiles win -- as long as they come from more threads rather
+// than more rounds (registers).  Same-run A/B on config 2 / K=14: 128 threads 2.83 / 6.85 ms, 256: 2.45 / 4.47,
+// 512: 2.05 / 3.52, 1024: 1.94 / 3.31.
+template <class ET, int RIPT, int RNT>
+__global__ __launch_bounds__(RNT, 4) void k_rle(const ET *ent, uint32_t *scal, u64 *status, const uint32_t *rec_total,
                                                uint64_t first_col, uint64_t M, uint64_t max_nz, float *data, uint64_t *col_ind,
                                                uint64_t *row_ind, FillTask *tasks, uint32_t task_cap, const uint32_t *regions,
                                                int key_shift) {
     constexpr bool NARROW = sizeof(ET) == 4;
-    constexpr int R_TILE = NT * RIPT, R_WCHUNK = 64 * RIPT;
+    constexpr int R_TILE = RNT * RIPT, R_WCHUNK = 64 * RIPT, RNW = RNT / 64;
     __shared__ uint32_t sreg[NARROW ? RADIX + 1 : 1];
     __shared__ uint32_t s_tile;
-    __shared__ uint32_t s_cnt[NW], s_first[NW];
+    __shared__ uint32_t s_cnt[RNW], s_first[RNW];
     __shared__ uint32_t s_next;   // first head after this tile (index), E if none
     __shared__ u64 s_out0;        // heads before this tile
     const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
@@ -1223,7 +1229,7 @@ __global__ __launch_bounds__(NT, 4) void k_rle(const ET *ent, uint32_t *scal, u6
     const uint32_t E = scal[0];
     if (tid == 0) s_tile = atomicAdd(&scal[5], 1u);
     if constexpr (NARROW)
-        for (uint32_t i = tid; i <= RADIX; i += NT) sreg[i] = regions[i];
+        for (uint32_t i = tid; i <= RADIX; i += RNT) sreg[i] = regions[i];
     lds_sync();
     const uint32_t tile = s_tile;
     if (E == 0) {  // no instance at all: every row pointer is 0
@@ -1268,7 +1274,7 @@ __global__ __launch_bounds__(NT, 4) void k_rle(const ET *ent, uint32_t *scal, u6
     }
     const ET carry0 = (wbase_i > 0 && lane == 0) ? ent[wbase_i - 1] : (ET)0;
     ET probe = 0;
-    if (w == NW - 1 && tile_end + lane < E) probe = ent[tile_end + lane];
+    if (w == RNW - 1 && tile_end + lane < E) probe = ent[tile_end + lane];
 
     // does a region start inside this wave's chunk (or exactly at its first entry)?  Nearly never: 256 regions.
     bool has_b = false;
@@ -1310,7 +1316,7 @@ __global__ __launch_bounds__(NT, 4) void k_rle(const ET *ent, uint32_t *scal, u6
     // The array is sorted (k-mer id major, column minor; narrow: by value inside a region), so that head is the first
     // entry greater than the tile's last one: the 64-entry probe loaded above (the common case), then a binary search
     // -- O(log E) even when one run spans the rest of the array (a single poly-A record of any length).
-    if (w == NW - 1) {
+    if (w == RNW - 1) {
         uint32_t nxt = E;
         if (tile_end < E) {
             const ET last = __shfl(e[RIPT - 1], 63);  // entry tile_end - 1 (the tile is full)
@@ -1338,7 +1344,7 @@ __global__ __launch_bounds__(NT, 4) void k_rle(const ET *ent, uint32_t *scal, u6
     lds_sync();
     uint32_t wave_before = 0, n_heads = 0;
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
+    for (int i = 0; i < RNW; ++i) {
         const uint32_t t = s_cnt[i];
         if ((uint32_t)i < w) wave_before += t;
         n_heads += t;
@@ -1357,7 +1363,7 @@ __global__ __launch_bounds__(NT, 4) void k_rle(const ET *ent, uint32_t *scal, u6
     // first head after this wave's chunk
     uint32_t after = s_next;
 #pragma unroll
-    for (int i = NW - 1; i >= 1; --i)
+    for (int i = RNW - 1; i >= 1; --i)
         if ((uint32_t)i > w && s_first[i] != NONE) after = s_first[i];
 
     // ---- emit.  nxt_after = first head in rounds > j (wave-uniform), walked backwards
@@ -1832,7 +1838,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
             ei = eo, eo = t;
             final_regions = regs1;
         }
-        hipLaunchKernelGGL((k_rle<uint32_t, RLE_IPT_NARROW>), dim3((uint32_t)(((uint64_t)l.n_tiles * TILE + NT * RLE_IPT_NARROW - 1) / (NT * RLE_IPT_NARROW))), block, 0, s, (const uint32_t *)ei, scal, status, (const uint32_t *)total, first_col, M,
+        hipLaunchKernelGGL((k_rle<uint32_t, RLE_IPT_NARROW, RLE_NT>), dim3((uint32_t)(((uint64_t)l.n_tiles * TILE + RLE_NT * RLE_IPT_NARROW - 1) / (RLE_NT * RLE_IPT_NARROW))), dim3(RLE_NT), 0, s, (const uint32_t *)ei, scal, status, (const uint32_t *)total, first_col, M,
                            max_nz, d_data, d_col_ind, d_row_ind, tasks, l.task_cap, final_regions, n_pass > 1 ? 8 : 0);
     } else {
         u64 *ei = entA, *eo = entB;
@@ -1851,7 +1857,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
             u64 *t = ei;
             ei = eo, eo = t;
         }
-        hipLaunchKernelGGL((k_rle<u64, RLE_IPT_WIDE>), dim3((uint32_t)(((uint64_t)l.n_tiles * TILE + NT * RLE_IPT_WIDE - 1) / (NT * RLE_IPT_WIDE))), block, 0, s, (const u64 *)ei, scal, status, (const uint32_t *)total, first_col, M, max_nz,
+        hipLaunchKernelGGL((k_rle<u64, RLE_IPT_WIDE, RLE_NT>), dim3((uint32_t)(((uint64_t)l.n_tiles * TILE + RLE_NT * RLE_IPT_WIDE - 1) / (RLE_NT * RLE_IPT_WIDE))), dim3(RLE_NT), 0, s, (const u64 *)ei, scal, status, (const uint32_t *)total, first_col, M, max_nz,
                            d_data, d_col_ind, d_row_ind, tasks, l.task_cap, (const uint32_t *)nullptr, 0);
     }
     pt.mark("k_rle");
