@@ -463,22 +463,31 @@ __global__ __launch_bounds__(NT) void k_hist_bases(BasesArgs a, uint32_t *tilehi
     }
 }
 
-// y for K >= 9, pass 0 histogram: digit = low byte of the sort key id >> low_bits, per tile of 8192 positions
-// (= NT packed words, one per thread, decoded from registers: the order inside a tile does not matter here).
-__global__ __launch_bounds__(NT) void k_hist_words_y(BasesArgs a, uint32_t *tilehist, uint32_t n_tiles) {
-    __shared__ uint32_t h[2][NW][RADIX];
+// y for K >= 9, pass 0 histogram: digit = low byte of the sort key id >> low_bits, per tile of BNT packed words
+// (= 16 BNT positions, one word per thread, decoded from registers: the order inside a tile does not matter here).
+// The chunk holds n_words8 = 512 * (its number of 8192-position tiles) words; a last tile may be partly outside.
+template <int BNT>
+__device__ __forceinline__ WordWindows yword_fetch(const BasesArgs &a, uint32_t tile, uint64_t n_words8) {
+    const uint64_t lw = (uint64_t)tile * BNT + threadIdx.x;  // word inside the chunk
+    return (lw < n_words8) ? word_fetch(a, a.tile0 * NT + lw) : WordWindows{0u, 0u, 0u};
+}
+
+template <int BNT>
+__global__ __launch_bounds__(BNT) void k_hist_words_y(BasesArgs a, uint32_t *tilehist, uint64_t n_words8, uint32_t n_tiles) {
+    constexpr int BNW = BNT / 64;
+    __shared__ uint32_t h[2][BNW][RADIX];
     const uint32_t tid = threadIdx.x, w = tid >> 6;
     const uint32_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
     const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
     if (t0 >= t1) return;
-    WordWindows nx = word_fetch(a, (a.tile0 + t0) * NT + tid);
-    for (uint32_t i = tid; i < NW * RADIX; i += NT) (&h[0][0][0])[i] = 0;
+    WordWindows nx = yword_fetch<BNT>(a, t0, n_words8);
+    for (uint32_t i = tid; i < BNW * RADIX; i += BNT) (&h[0][0][0])[i] = 0;
     lds_sync();
     for (uint32_t tile = t0; tile < t1; ++tile) {
         uint32_t(*const hc)[RADIX] = h[(tile - t0) & 1u];
         uint32_t(*const hn)[RADIX] = h[((tile - t0) & 1u) ^ 1u];
         const WordWindows x = nx;
-        if (tile + 1 < t1) nx = word_fetch(a, (a.tile0 + tile + 1) * NT + tid);
+        if (tile + 1 < t1) nx = yword_fetch<BNT>(a, tile + 1, n_words8);
         uint32_t run_d = NONE, run_len = 0;  // equal consecutive digits (poly-A) are added once
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -494,15 +503,92 @@ __global__ __launch_bounds__(NT) void k_hist_words_y(BasesArgs a, uint32_t *tile
             }
         }
         if (run_d != NONE) atomicAdd(&hc[w][run_d], run_len);
-        for (uint32_t i = tid; i < NW * RADIX; i += NT) (&hn[0][0])[i] = 0;  // the other table, for the next tile
+        for (uint32_t i = tid; i < BNW * RADIX; i += BNT) (&hn[0][0])[i] = 0;  // the other table, for the next tile
         lds_sync();
         if (tid < RADIX) {
             uint32_t s = 0;
 #pragma unroll
-            for (int i = 0; i < NW; ++i) s += hc[i][tid];
+            for (int i = 0; i < BNW; ++i) s += hc[i][tid];
             tilehist[(uint64_t)tile * RADIX + tid] = s;
         }
         lds_sync();  // the next tile zeroes hc right after its atomics: the readers above must be done first
+    }
+}
+
+// y for K >= 13, pass 0 partition with 4-byte entries ((sort key >> 8) << 24 | low bits): the order-free scheme of
+// k_scatter<..YKEYS..> (windows from registers, the rank from one returning LDS atomic) in 1024-thread workgroups on
+// tiles of 16,384 positions.  The write-out of this pass is store-bound and its runs are twice as long this way:
+// 2.17 -> 1.79 ms on the bench's reads (the 2-byte payloads of K <= 12 do better with the 8192-position tiles of
+// k_scatter, two workgroups per CU).
+template <class ET, int BNT>
+__global__ __launch_bounds__(BNT) void k_yscatter(BasesArgs a, const uint32_t *tilebase, uint64_t n_words8, uint32_t n_tiles, ET *out) {
+    constexpr int BNW = BNT / 64, BTILE = BNT * 16;
+    __shared__ __attribute__((aligned(16))) ET sent[BTILE];
+    __shared__ uint8_t saux[BTILE];
+    __shared__ uint32_t cnt[RADIX], gadj[RADIX], swave[BNW];
+    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
+    const uint32_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    if (t0 >= t1) return;
+    const uint32_t low_mask = (1u << a.low_bits) - 1u;
+    WordWindows nx = yword_fetch<BNT>(a, t0, n_words8);
+    uint32_t gb = (tid < RADIX) ? tilebase[(uint64_t)t0 * RADIX + tid] : 0u;
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+        if (tid < RADIX) cnt[tid] = 0;
+        lds_sync();
+        const WordWindows x = nx;
+        if (tile + 1 < t1) nx = yword_fetch<BNT>(a, tile + 1, n_words8);
+        uint32_t rank[16];  // bits 0..15 the rank inside the digit, bits 16..23 the digit; NONE = no k-mer
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            uint32_t key;
+            rank[j] = NONE;
+            if (word_window(x, j, a.K, key)) {
+                const uint32_t d = (key >> a.low_bits) & 255u;
+                rank[j] = atomicAdd(&cnt[d], 1u) | (d << 16);
+            }
+        }
+        lds_sync();
+        // exclusive scan of the 256 digit counts (waves 0..3 hold them), tile total
+        uint32_t dtot = (tid < RADIX) ? cnt[tid] : 0u, inc = dtot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o);
+            if (lane >= (uint32_t)o) inc += t;
+        }
+        if (lane == 63) swave[w] = inc;
+        lds_sync();
+        uint32_t wbase = 0, tile_count = 0;
+#pragma unroll
+        for (int i = 0; i < RADIX / 64; ++i) {
+            const uint32_t t = swave[i];
+            if ((uint32_t)i < w) wbase += t;
+            tile_count += t;
+        }
+        if (tid < RADIX) {
+            const uint32_t dstart = wbase + inc - dtot;
+            cnt[tid] = dstart;
+            gadj[tid] = gb - dstart;
+            if (tile + 1 < t1) gb = tilebase[(uint64_t)(tile + 1) * RADIX + tid];
+        }
+        lds_sync();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (rank[j] != NONE) {
+                uint32_t key;
+                (void)word_window(x, j, a.K, key);
+                const uint32_t d = (rank[j] >> 16) & 255u, sk = key >> a.low_bits;
+                const uint32_t slot = cnt[d] + (rank[j] & 0xFFFFu);
+                if constexpr (sizeof(ET) == 2)
+                    sent[slot] = (ET)(key & low_mask);
+                else
+                    sent[slot] = (ET)(((sk >> 8) << 24) | (key & low_mask));
+                saux[slot] = (uint8_t)d;
+            }
+        }
+        lds_sync();
+        for (uint32_t i = tid; i < tile_count; i += BNT) out[gadj[saux[i]] + i] = sent[i];
+        lds_sync();
     }
 }
 
@@ -1719,14 +1805,19 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         const dim3 pgrid(nt < (uint32_t)PERSIST_BLOCKS ? nt : (uint32_t)PERSIST_BLOCKS);
         const dim3 hgrid(nt < 2048u ? nt : 2048u);
         const uint32_t *c_hist = hist, *c_E = &scal[0];
-        hipLaunchKernelGGL(k_hist_words_y, hgrid, block, 0, s, a, hist, nt);
-        pt.mark("k_hist_words_y");
-        if (int rc = scan_tilehist(hist, nt, bsum, &scal[0], s)) return rc;
-        pt.mark("k_scan");
-        hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, nt, c_E, regs0);
+        // pass 0 tiles: 8192 positions (512 threads) for the 2-byte payloads, 16,384 (1024 threads) for 4-byte entries
+        const uint64_t n_words8 = (uint64_t)nt * NT;
+        const uint32_t nt0 = two_pass ? (nt + 1) / 2 : nt;
         if (two_pass)
-            hipLaunchKernelGGL((k_scatter<true, uint32_t, true, 1, false>), pgrid, block, 0, s, a, (const uint32_t *)nullptr, c_E, 0,
-                               c_hist, nt, entA, (const uint32_t *)nullptr);
+            hipLaunchKernelGGL(k_hist_words_y<1024>, dim3(nt0 < 1024u ? nt0 : 1024u), dim3(1024), 0, s, a, hist, n_words8, nt0);
+        else
+            hipLaunchKernelGGL(k_hist_words_y<NT>, hgrid, block, 0, s, a, hist, n_words8, nt0);
+        pt.mark("k_hist_words_y");
+        if (int rc = scan_tilehist(hist, nt0, bsum, &scal[0], s)) return rc;
+        pt.mark("k_scan");
+        hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, nt0, c_E, regs0);
+        if (two_pass)
+            hipLaunchKernelGGL((k_yscatter<uint32_t, 1024>), dim3(nt0 < 256u ? nt0 : 256u), dim3(1024), 0, s, a, c_hist, n_words8, nt0, entA);
         else  // one pass: 2-byte payloads
             hipLaunchKernelGGL((k_scatter<true, uint32_t, true, 1, true>), pgrid, block, 0, s, a, (const uint32_t *)nullptr, c_E, 0,
                                c_hist, nt, entA, (const uint32_t *)nullptr);
