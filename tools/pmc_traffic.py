@@ -16,7 +16,7 @@ from collections import defaultdict
 root, workload = sys.argv[1], sys.argv[2]
 LABEL = [  # kernel symbol (regex) -> the label of bench.py's per-kernel table
     (r"k_rle<", "k_rle"),
-    (r"k_scatter<true, unsigned int, true", "k_scatter<bases,y>"),
+    (r"k_scatter<true, unsigned int, true|k_yscatter", "k_scatter<bases,y>"),
     (r"k_scatter<true", "k_scatter<bases>"),
     (r"k_scatter<false", "k_scatter<entries>"),
     (r"k_hist_words_y", "k_hist_words_y"),
