@@ -609,7 +609,7 @@ __global__ __launch_bounds__(NT) void k_hist_entries(const ET *ent, const uint32
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             const uint64_t i = (uint64_t)t * TILE + w * WCHUNK + j * 64 + lane;
-            e[j] = (i < E) ? ent[i] : (ET)0;
+            e[j] = (i < E) ? __builtin_nontemporal_load(&ent[i]) : (ET)0;  // (same-run A/B: 0.365 -> 0.315, 1.87 -> 1.72 ms)
         }
     };
     load_tile(t0);
