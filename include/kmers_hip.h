@@ -12,6 +12,7 @@
  *   device y      kmers_hip_count_y  packed store -> dense int32 histogram   (replaces count_kmers :320-328)
  *   device X      kmers_hip_build_x  packed store -> CSR (data,row_ind,col_ind)
  *                                    (replaces collect_kmers/fill_indices_coo :218-238 and to_csr :77-169)
+ *   device model  kmers_hip_model_*  X and y in HBM -> logp_grad's two sparse products (kmerexpr/utils.py:76-108)
  */
 #ifndef KMERS_HIP_H
 #define KMERS_HIP_H
@@ -144,6 +145,40 @@ int kmers_csr_merge(int n_parts, uint64_t n_rows, const float *const data[], con
  * write the file) or KMERS_ERR_BAD_ARG. */
 int kmers_npz_write_csr(const char *path, const float *data, const uint64_t *col_ind, const uint64_t *row_ind,
                         uint64_t nnz, uint64_t n_rows, uint64_t n_cols);
+
+/* ---- the step after the path: logp_grad's two sparse products on the resident X ---- */
+
+/* Device-side state of the reference's multinomial_simplex_model (kmerexpr/multinomial_simplex_model.py:56-62):
+ * ymask = y.nonzero(), xnnz = x[ymask] (a CSR with 32-bit indices, plus a copy sorted by column for the transposed
+ * product), ynnz = y[ymask] / sum(y) (float64).  Everything lives in HBM until kmers_hip_model_free. */
+typedef struct kmers_model kmers_model;
+
+/* Build the model from X as kmers_hip_build_x left it in HBM (d_data f32[nnz], d_col_ind u64[nnz],
+ * d_row_ind u64[n_rows + 1]) and the histogram d_y int32[n_rows] of kmers_hip_count_y.  Allocates (library-owned
+ * device memory, about 16 bytes per non-zero of xnnz plus 24 per masked row; twice that while it is being built)
+ * and synchronises `stream`.  Limits: n_cols, masked rows and non-zeros of xnnz below 2^32 (KMERS_ERR_TOO_LARGE);
+ * y must have a non-zero (KMERS_ERR_BAD_ARG). */
+int kmers_hip_model_create(const float *d_data, const uint64_t *d_col_ind, const uint64_t *d_row_ind, uint64_t n_rows,
+                           uint64_t n_cols, const int32_t *d_y, void *stream, kmers_model **out);
+void kmers_hip_model_free(kmers_model *m);
+uint64_t kmers_hip_model_n_masked(const kmers_model *m);   /* rows of xnnz = number of non-zeros of y          */
+uint64_t kmers_hip_model_nnz(const kmers_model *m);        /* non-zeros of xnnz                                */
+int64_t kmers_hip_model_sum_y(const kmers_model *m);       /* the reference's self.N                           */
+const uint32_t *kmers_hip_model_rows(const kmers_model *m);   /* device: ymask, u32[n_masked], ascending        */
+const float *kmers_hip_model_xtheta(const kmers_model *m);    /* device: xnnz.theta of the last call, f32[n_masked] */
+
+/* Copy rows (what = 0, uint32[n_masked]) or xtheta (what = 1, float32[n_masked]) to host memory; synchronous. */
+int kmers_hip_model_read(const kmers_model *m, int what, void *host_dst);
+
+/* The data terms of logp_grad (kmerexpr/utils.py:76-108) for theta = d_theta f32[n_cols] (device):
+ *   xtheta = xnnz.theta (:92), *val_out = sum ynnz*log(xtheta) (:93, host double),
+ *   unless nograd: d_grad f32[n_cols] (device) = (ynnz / xtheta).xnnz (:102-103).
+ * Sums are accumulated in float64 and rounded to float32 once (the reference's MKL float32 products round per
+ * operation), in a fixed order: the same inputs give the same bits on every call.  The (beta - 1) terms (:94-96,
+ * :104-106) are O(n_cols) arithmetic on the caller's theta and are not computed here.
+ * Synchronises `stream` (val is read back).  Calls on one model must not overlap. */
+int kmers_hip_model_logp_grad(kmers_model *m, const float *d_theta, int nograd, double *val_out, float *d_grad,
+                              void *stream);
 
 #ifdef __cplusplus
 }

@@ -91,6 +91,19 @@ def handle():
     lib.kmers_csr_merge.argtypes = [C.c_int, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp, vp]
     lib.kmers_npz_write_csr.restype = C.c_int
     lib.kmers_npz_write_csr.argtypes = [C.c_char_p, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64]
+    lib.kmers_hip_model_create.restype = C.c_int
+    lib.kmers_hip_model_create.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp, C.POINTER(vp)]
+    lib.kmers_hip_model_free.restype, lib.kmers_hip_model_free.argtypes = None, [vp]
+    for name in ("n_masked", "nnz"):
+        f = getattr(lib, "kmers_hip_model_" + name)
+        f.restype, f.argtypes = C.c_uint64, [vp]
+    lib.kmers_hip_model_sum_y.restype, lib.kmers_hip_model_sum_y.argtypes = C.c_int64, [vp]
+    for name in ("rows", "xtheta"):
+        f = getattr(lib, "kmers_hip_model_" + name)
+        f.restype, f.argtypes = vp, [vp]
+    lib.kmers_hip_model_read.restype, lib.kmers_hip_model_read.argtypes = C.c_int, [vp, C.c_int, vp]
+    lib.kmers_hip_model_logp_grad.restype = C.c_int
+    lib.kmers_hip_model_logp_grad.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_double), vp, vp]
     lib.kmers_hip_profile_enable.restype, lib.kmers_hip_profile_enable.argtypes = None, [C.c_int]
     lib.kmers_hip_profile_count.restype, lib.kmers_hip_profile_count.argtypes = C.c_int, []
     lib.kmers_hip_profile_get.restype = C.c_int

@@ -1,0 +1,57 @@
+"""`multinomial_simplex_model` with the reference's constructor and `logp_grad` (reference
+kmerexpr/multinomial_simplex_model.py:10-95, kmerexpr/utils.py:76-108), X and y resident in HBM.
+
+The reference's solvers (`fit` -> exp_grad_solver / mg, multinomial_simplex_model.py:117-146) only ever call
+`model.logp_grad(theta, nograd=...)` and the `initialize_iterates_*` helpers; they are host-side Python outside this
+library's scope and run unchanged on an instance of this class."""
+import numpy as np
+
+from .model import DeviceModel
+from .transcriptome_reader import load_xy
+
+
+class multinomial_simplex_model:
+    def __init__(self, x_file=None, y_file=None, beta=1.0, lengths=None, solver_name="exp_grad", device="cuda"):
+        """Same arguments as the reference (multinomial_simplex_model.py:42-44); x_file / y_file may also be a scipy
+        CSR matrix / an ndarray, as its load_xy allows (transcriptome_reader.py:6-16)."""
+        import torch
+        x, y = load_xy(x_file, y_file)
+        assert len(x.shape) == 2 and len(y.shape) == 1 and y.shape[0] == x.shape[0]
+        self.M, self.T = x.shape
+        self.N = np.sum(y)
+        self.beta = beta
+        self.name = "mirror"
+        self.solver_name = solver_name
+        if lengths is not None:
+            assert len(lengths) == self.T
+            self.lengths = lengths
+        else:
+            self.lengths = np.ones(self.T)
+        self._torch = torch
+        self.device_model = DeviceModel.from_host(x, y, device)
+        self._theta = torch.empty(self.T, dtype=torch.float32, device=self.device_model.device)
+
+    def logp_grad(self, theta, nograd=False):
+        """reference kmerexpr/utils.py:76-108: the data terms on the GPU, the (beta - 1) terms here as there."""
+        theta = np.asarray(theta).astype(np.float32)
+        self._theta.copy_(self._torch.from_numpy(theta))
+        out = self.device_model.logp_grad(self._theta, nograd=nograd)
+        val = out if nograd else out[0]
+        beta, lengths = self.beta, self.lengths
+        mask = theta > 0
+        thetamask = theta[mask]
+        if beta != 1.0:
+            val += (beta - 1.0) * np.sum(np.log(thetamask / lengths[mask]))
+            val -= (beta - 1.0) * np.log(np.sum(thetamask / lengths[mask]))
+        if nograd:
+            return val
+        grad = out[1].cpu().numpy()
+        if beta != 1.0:
+            grad[mask] += (beta - 1.0) / thetamask
+            grad[mask] -= (beta - 1.0) / (np.sum(thetamask / lengths[mask]) * lengths[mask])
+        return val, grad
+
+    def initialize_iterates_uniform(self, lengths=None):
+        """reference multinomial_simplex_model.py:97-101"""
+        alpha = np.ones(self.T)
+        return alpha / alpha.sum()

@@ -1,0 +1,162 @@
+"""logp_grad's two sparse products on the resident X (kmers_hip_model_* of
+include/kmers_hip.h) against the float64 restatement of the reference's logp_grad_ref (oracle/logp_grad.py,
+reference kmerexpr/utils.py:46-73).
+
+Tolerance (floating point, so stated here): the kernels accumulate in float64 and round to float32 once, the oracle
+works in float64 on the same float32 inputs (rounding xtheta and w to float32 where the reference stores them in its
+float32 scratch array), so xtheta agrees to one float32 rounding (rtol 2e-7), the gradient to
+the roundings of xtheta, w and the result (rtol 1e-6), and val = sum ynnz*log(xtheta) with sum ynnz = 1 to
+atol 5e-7.  Parity is not pinned by reference fixtures (none exist for this function, see oracle/logp_grad.py); the
+properties the reference's tests name are checked as well.  Needs a real MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+from scipy.sparse import csr_matrix
+
+from kmers_amd import synth
+from oracle import logp_grad as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def syn(tmp_path_factory):
+    d = tmp_path_factory.mktemp("model")
+    iso = str(d / "iso.fsa")
+    info = synth.synth_transcriptome(iso, n_records=3000, total_bases=3_000_000, seed=11, return_sequences=True)
+    reads = str(d / "reads.fsa")
+    synth.synth_reads(reads, info["concat"], info["offsets"], 30000, read_len=100, seed=5)
+    other = str(d / "other.fsa")
+    synth.synth_transcriptome(other, n_records=40, total_bases=40_000, seed=99)
+    return dict(iso=iso, reads=reads, other=other)
+
+
+def xy(syn, K, reads="reads"):
+    from kmers_amd.libkmers import fasta_count_kmers, fasta_to_kmers_csr
+    data, row_ind, col_ind, n_cols = fasta_to_kmers_csr(syn["iso"], K)
+    x = csr_matrix((data, col_ind.astype(np.int64), row_ind.astype(np.int64)), shape=(4 ** K, n_cols), dtype=np.float32)
+    return x, fasta_count_kmers(syn[reads], K)
+
+
+def thetas(T, seed):
+    rng = np.random.default_rng(seed)
+    yield np.ones(T) / T
+    yield rng.dirichlet(np.full(T, 0.5))
+    t = rng.dirichlet(np.full(T, 1.0))
+    t[rng.random(T) < 0.1] = 0.0            # zeros: masked out of the beta terms, plain zeros in the products
+    yield t / t.sum()
+
+
+def check(model, x, y, theta, beta=1.0, lengths=None):
+    rows, xnnz, ynnz = orc.model_setup(x, y)
+    lengths = np.ones(x.shape[1]) if lengths is None else lengths
+    want_val, want_grad, want_xt = orc.logp_grad_ref(theta, beta, xnnz, ynnz, lengths)
+    val, grad = model.logp_grad(theta)
+    dm = model.device_model
+    assert np.array_equal(dm.rows(), rows)
+    assert dm.n_masked == rows.shape[0] and dm.nnz == xnnz.nnz and dm.sum_y == int(y.sum())
+    np.testing.assert_allclose(dm.xtheta(), want_xt, rtol=2e-7, atol=1e-45)    # atol: float32 subnormals
+    assert grad.dtype == np.float32 and grad.shape == (x.shape[1],)
+    if np.isfinite(want_val):
+        np.testing.assert_allclose(val, want_val, rtol=0, atol=5e-7)
+        np.testing.assert_allclose(grad, want_grad, rtol=1e-6, atol=1e-30)
+    else:                                    # a read k-mer with probability 0 under theta: log(0), as in the reference
+        assert val == want_val
+        fin = np.isfinite(want_grad)
+        assert np.array_equal(np.isfinite(grad), fin)
+        np.testing.assert_allclose(grad[fin], want_grad[fin], rtol=1e-6, atol=1e-30)
+    assert model.logp_grad(theta, nograd=True) == val
+    val2, grad2 = model.logp_grad(theta)     # fixed summation order: the same bits on every call
+    assert val2 == val and np.array_equal(grad2.view(np.uint32), grad.view(np.uint32))
+    return val, grad
+
+
+@pytest.mark.parametrize("K", [1, 3, 6, 8, 11, 12, 14])
+def test_logp_grad_vs_oracle(syn, K):
+    from kmers_amd.multinomial_simplex_model import multinomial_simplex_model
+    x, y = xy(syn, K)
+    model = multinomial_simplex_model(x, y)
+    assert model.M == 4 ** K and model.T == x.shape[1] and model.N == y.sum()
+    for theta in thetas(model.T, K):
+        check(model, x, y, theta)
+
+
+def test_beta_terms_and_lengths(syn):
+    from kmers_amd.multinomial_simplex_model import multinomial_simplex_model
+    x, y = xy(syn, 7)
+    lengths = np.random.default_rng(3).integers(300, 5000, x.shape[1]).astype(np.float64)
+    model = multinomial_simplex_model(x, y, beta=1.5, lengths=lengths)
+    for theta in thetas(model.T, 1):
+        check(model, x, y, theta, beta=1.5, lengths=lengths)
+
+
+def test_columns_are_stochastic(syn):
+    """The reference's test_simplex (test/test_transcriptome_reader.py:52-64): sum(X . theta) == 1 on the simplex.
+    At K=3 every row has a read, so xnnz is all of X."""
+    from kmers_amd.multinomial_simplex_model import multinomial_simplex_model
+    x, y = xy(syn, 3)
+    assert np.all(y > 0)
+    model = multinomial_simplex_model(x, y)
+    for theta in thetas(model.T, 4):
+        model.logp_grad(theta, nograd=True)
+        assert abs(float(model.device_model.xtheta().astype(np.float64).sum()) - 1.0) < 1e-6
+
+
+def test_gradient_against_finite_differences(syn):
+    """What the reference's check_gradient does (test/test_multinomial_simplex_model.py): directional derivatives of
+    val against grad, here with val from the GPU as well."""
+    from kmers_amd.multinomial_simplex_model import multinomial_simplex_model
+    x, y = xy(syn, 8)
+    model = multinomial_simplex_model(x, y)
+    rng = np.random.default_rng(0)
+    theta = rng.dirichlet(np.full(model.T, 1.0)) + 1e-4
+    theta = (theta / theta.sum()).astype(np.float32).astype(np.float64)
+    val, grad = model.logp_grad(theta)
+    rows, xnnz, ynnz = orc.model_setup(x, y)
+    for _ in range(3):
+        d = rng.standard_normal(model.T) * theta
+        eps = 1e-3
+        fp = orc.logp_grad_ref(theta * (1 + 0) + eps * d, 1.0, xnnz, ynnz, model.lengths, nograd=True)
+        fm = orc.logp_grad_ref(theta - eps * d, 1.0, xnnz, ynnz, model.lengths, nograd=True)
+        # float32 rounding of theta +- eps d inside logp_grad_ref limits the agreement
+        assert abs((fp - fm) / (2 * eps) - float(grad.astype(np.float64) @ d)) < 2e-3 * max(1.0, abs(float(grad @ d)))
+
+
+def test_reads_outside_the_transcriptome(syn):
+    """Read k-mers that no isoform holds are empty rows of xnnz: xtheta = 0 there, val = -inf and w = inf, exactly
+    what the reference computes; plus empty rows in front of / behind all non-zeros."""
+    from kmers_amd.multinomial_simplex_model import multinomial_simplex_model
+    x, y = xy(syn, 12, reads="other")
+    rows, xnnz, ynnz = orc.model_setup(x, y)
+    assert (np.diff(xnnz.indptr) == 0).sum() > 100
+    model = multinomial_simplex_model(x, y)
+    val, grad = check(model, x, y, np.ones(model.T) / model.T)
+    assert val == -np.inf
+
+
+def test_device_resident_route(syn):
+    """X and y never leave HBM: DeviceStore.build_x / count_y buffers straight into the model."""
+    import torch
+    from kmers_amd.model import DeviceModel
+    from kmers_amd.store import MODE_X, MODE_Y_FASTA, Store
+    K = 10
+    xs = Store(syn["iso"], MODE_X).to_device()
+    buf = xs.x_buffers(K, xs.n_pos)
+    nnz = xs.build_x(buf)
+    counts = Store(syn["reads"], MODE_Y_FASTA).to_device().count_y(K)
+    dm = DeviceModel(buf["data"], buf["col_ind"], buf["row_ind"], xs.n_rec_total, counts)
+    x, y = xy(syn, K)
+    assert nnz == x.nnz
+    rows, xnnz, ynnz = orc.model_setup(x, y)
+    theta = np.random.default_rng(2).dirichlet(np.full(x.shape[1], 0.5)).astype(np.float32)
+    want_val, want_grad, want_xt = orc.logp_grad_ref(theta, 1.0, xnnz, ynnz, np.ones(x.shape[1]))
+    val, grad = dm.logp_grad(torch.from_numpy(theta).cuda())
+    np.testing.assert_allclose(dm.xtheta(), want_xt, rtol=2e-7)
+    np.testing.assert_allclose(val, want_val, atol=5e-7)
+    np.testing.assert_allclose(grad.cpu().numpy(), want_grad, rtol=1e-6, atol=1e-30)
+
+
+def test_all_zero_y_is_rejected(syn):
+    from kmers_amd.multinomial_simplex_model import multinomial_simplex_model
+    x, y = xy(syn, 4)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        multinomial_simplex_model(x, np.zeros_like(y))
