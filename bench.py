@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the k-mer hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload x8|x14|x12|y12|y8|y14]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload x8|x14|x12|y12|y8|y14|g8|g14]
 
 A step = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
   x8  (default) BASELINE.json configs[1]: synthetic GRCh38-RefSeq-shaped transcriptome, ~170k isoforms / ~400 Mbases,
       K=8 -> CSR X (kmers_hip_build_x: shred, stable radix partition, run-length reduce, emit)
   x14 configs[2]: the same transcriptome at K=14
   y12 configs[3] per-GPU share: simulated 100 bp reads -> dense int32 histogram at K=12 (kmers_hip_count_y)
+  g8, g14 (not a BASELINE.json config): one logp_grad evaluation (X.theta, the log-likelihood
+      term and X^T.(y / X.theta)) on the X and y of the configs above, resident in HBM; unit non-zeros/s; replicas only
 For N > 1 (one process per GPU, torchrun) every rank works on its own shard of the same shape (weak scaling: X column
 shards need no collective; y shards are summed with one RCCL all-reduce inside the timed step).
 Rank 0 prints ONE JSON line.  `value` is k-mers/s over all ranks, a k-mer being one window position
@@ -34,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="x8", help="x<K> or y<K>, K in 1..16 (x8, x14, y12 are BASELINE.json's)")
+    ap.add_argument("--workload", default="x8", help="x<K>, y<K> or g<K>, K in 1..16 (x8, x14, y12 are BASELINE.json's)")
     ap.add_argument("--records", type=int, default=170_000)
     ap.add_argument("--bases", type=int, default=400_000_000)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU for the y workloads")
@@ -42,8 +44,8 @@ def parse():
     ap.add_argument("--cache", default=os.environ.get("KMERS_BENCH_CACHE", "/tmp/kmers_bench"))
     args = ap.parse_args()
     import re
-    if not re.fullmatch(r"[xy]([1-9]|1[0-6])", args.workload):
-        ap.error("--workload must be x<K> or y<K> with K in 1..16")
+    if not re.fullmatch(r"[xyg]([1-9]|1[0-6])", args.workload):
+        ap.error("--workload must be x<K>, y<K> or g<K> with K in 1..16")
     return args
 
 
@@ -125,6 +127,99 @@ def cpu_baseline(args, K, kind_x):
                       f"{dt:.1f} s wall, file in page cache"}
 
 
+def bench_model(args, K, dev, rank, world, fence):
+    """g<K>: logp_grad on the resident X and y (kmers_hip_model_*).  Every rank runs the same evaluation on its own
+    shard-shaped inputs (replicas only: the fit's theta is global, sharding it is the solver's business)."""
+    import torch
+    from kmers_amd import _lib
+    from kmers_amd.model import DeviceModel
+    from kmers_amd.store import MODE_X, MODE_Y_FASTA, Store
+    iso, reads = make_inputs(args, rank, want_reads=True)
+    xs = Store(iso, MODE_X)
+    dx = xs.to_device(dev)
+    buf = dx.x_buffers(K, xs.n_windows(K))
+    nnz_x = dx.build_x(buf)
+    buf["workspace"] = None
+    ys = Store(reads, MODE_Y_FASTA)
+    counts = ys.to_device(dev).count_y(K)
+    torch.cuda.synchronize()
+    T = xs.n_rec_total
+    t0 = time.perf_counter()
+    dm = DeviceModel(buf["data"], buf["col_ind"], buf["row_ind"], T, counts)
+    setup_s = time.perf_counter() - t0
+    theta = torch.full((T,), 1.0 / T, dtype=torch.float32, device=dev)
+    val = 0.0
+
+    def step():
+        nonlocal val
+        val, _ = dm.logp_grad(theta)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    _lib.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    table = _lib.profile_table()
+    _lib.profile(False)
+    if rank != 0:
+        return
+    ms_per_step = dt / args.steps * 1e3
+    nnz, n_m = dm.nnz, dm.n_masked
+    kernel_bytes = {      # per launch: 8 bytes per non-zero, row pointers in, one float per row out, the gathered vector once
+        "k_spmv<x.theta>": 8 * nnz + 4 * (n_m + 1) + 4 * n_m + 4 * T,
+        "k_spmv<w.x>": 8 * nnz + 4 * (T + 1) + 4 * T + 4 * n_m,
+        "k_logp_terms": (4 + 8 + 4) * n_m,
+    }
+    dom = max((r for r in table if r[0] in kernel_bytes), key=lambda r: r[1])
+    avg_ms = dom[1] / dom[2]
+    ach = kernel_bytes[dom[0]] / (avg_ms * 1e-3) / 1e9
+    path_bytes = sum(kernel_bytes.values())
+    out = {
+        "metric": "logp_grad non-zeros/s (X.theta + X^T.(y/X.theta) on the resident X; SURVEY.md 8f row 4)",
+        "value": 2 * nnz * world * args.steps / dt, "unit": "non-zeros/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 in, f64 accumulate", "data": "synthetic",
+        "config": {"workload": f"logp_grad K={K}: X of {T} isoforms / {xs.n_bases / 1e6:.0f} Mbases, y of {args.reads} "
+                               f"simulated 100 bp reads ({args.workload}; replicas only)",
+                   "K": K, "nnz_x": nnz_x, "masked_rows": n_m, "nnz_xnnz": nnz, "val": val,
+                   "model_setup_s": round(setup_s, 3), "parallelism": f"replicas{world}"},
+        "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(avg_ms, 4),
+                     "launches_per_step": dom[2] // max(args.steps, 1), "algorithmic_bytes": int(kernel_bytes[dom[0]])},
+        "path": {"algorithmic_bytes": int(path_bytes),
+                 "achieved_GBs": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 1)},
+        "kernels_ms": {r[0]: round(r[1] / args.steps, 4) for r in table},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        # the reference's products are MKL's (sparse_dot_mkl, absent here): scipy's CSR kernels on one core stand in,
+        # on the same xnnz downloaded from the GPU run's inputs
+        try:
+            from scipy.sparse import csr_matrix
+            n = nnz_x
+            x = csr_matrix((buf["data"][:n].cpu().numpy(), buf["col_ind"][:n].cpu().numpy(),
+                            buf["row_ind"].cpu().numpy()), shape=(4 ** K, T))
+            y = counts.cpu().numpy()
+            ymask = y.nonzero()
+            xnnz, ynnz = x[ymask], y[ymask] / y.sum()
+            th = np.full(T, 1.0 / T, np.float32)
+            t0 = time.perf_counter()
+            xt = xnnz.dot(th)
+            v = float(ynnz.dot(np.log(xt)))
+            g = (ynnz / xt).astype(np.float32) @ xnnz
+            cdt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": 2 * xnnz.nnz / cdt, "unit": "non-zeros/s", "cores": 1, "kind": "port",
+                                   "sample": f"the same logp_grad (utils.py:46-73 in scipy float32, single thread; the "
+                                             f"reference's MKL is absent), full size, {cdt:.2f} s, val {v:.6f}, "
+                                             f"|grad|_1 {float(np.abs(g).sum()):.4f}"}
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -150,6 +245,18 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+
+    if args.workload[0] == "g":
+        def fence0():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+        bench_model(args, K, dev, rank, world, fence0)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     iso, reads = make_inputs(args, rank, want_reads=not kind_x)
     st = Store(iso if kind_x else reads, MODE_X if kind_x else MODE_Y_FASTA)

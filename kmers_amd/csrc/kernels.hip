@@ -1549,6 +1549,18 @@ std::vector<ProfEntry> profile_snapshot() {
     return g_prof;
 }
 
+bool profile_on() { return g_prof_on; }
+void profile_add(const char *name, double ms) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &p : g_prof)
+        if (p.name == name) {
+            p.ms += ms;
+            p.calls += 1;
+            return;
+        }
+    g_prof.push_back(ProfEntry{name, ms, 1});
+}
+
 struct PhaseTimer {
     hipStream_t s;
     bool on;

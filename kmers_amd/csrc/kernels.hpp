@@ -17,6 +17,8 @@ struct ProfEntry {
 void profile_enable(bool on);
 void profile_reset();
 std::vector<ProfEntry> profile_snapshot();
+bool profile_on();
+void profile_add(const char *name, double ms);  // one launch of `name` took ms (model.hip's own event pairs)
 int read_stamps(unsigned long long *out16, bool reset);  // diagnostic builds (-DKK_STAMPS) only
 
 size_t x_workspace_bytes(uint64_t n_pos, uint64_t n_rec, int K);

@@ -20,6 +20,7 @@
 // the per-tile carries.  Sums are accumulated in double and rounded to float32 once.
 // Algorithmic bytes per non-zero: 8 (column + value) + the gathered vector (L2-resident up to a few MB).
 #include "kmers_hip.h"
+#include "kernels.hpp"
 
 #include <cstdio>
 #include <cstring>  // before rocprim: one of its iterator headers calls memset without including this
@@ -67,50 +68,59 @@ __device__ __forceinline__ u32 last_row_le(const P &ptr, u32 lo, u32 hi, u32 k) 
     return lo;
 }
 
+// first / last row with a non-zero in every tile, found once per model (the row structure never changes)
+__global__ __launch_bounds__(256) void k_tile_rows(const u32 *__restrict__ ptr, u32 n, u32 nnz, u32 n_tiles,
+                                                   uint2 *__restrict__ tile_rows) {
+    const u32 tile = blockIdx.x * 256 + threadIdx.x;
+    if (tile >= n_tiles) return;
+    auto gptr = [&](u32 r) { return ptr[r]; };
+    const u32 base = tile * SP_TILE, tile_end = min(base + SP_TILE, nnz);
+    const u32 lo = tile == 0 ? 0u : last_row_le(gptr, 0u, n - 1, base);  // tile 0 also owns the empty rows in front
+    tile_rows[tile] = make_uint2(lo, last_row_le(gptr, lo, n - 1, tile_end - 1));
+}
+
 // out[r] = sum_{k in [ptr[r], ptr[r+1])} val[k] * vec[idx[k]]     for r < n;  ptr[n] == nnz > 0
 __global__ __launch_bounds__(SP_NT) void k_spmv(const u32 *__restrict__ ptr, const u32 *__restrict__ idx,
-                                                const float *__restrict__ val, const float *__restrict__ vec, u32 n,
-                                                u32 nnz, float *__restrict__ out, TileCarry *__restrict__ carry) {
-    __shared__ u32 s_rows[2];
+                                                const float *__restrict__ val, const float *__restrict__ vec,
+                                                const uint2 *__restrict__ tile_rows, u32 n, u32 nnz,
+                                                float *__restrict__ out, TileCarry *__restrict__ carry) {
     __shared__ u32 s_ptr[SP_PTR_LDS];
     __shared__ double s_wave_a[SP_NT / 64];
     __shared__ u32 s_wave_f[SP_NT / 64];
     const u32 t = threadIdx.x, tile = blockIdx.x;
     const u32 base = tile * SP_TILE;
     const u32 tile_end = min(base + SP_TILE, nnz);
-    auto gptr = [&](u32 r) { return ptr[r]; };
-    if (t < 2) s_rows[t] = last_row_le(gptr, 0u, n - 1, t == 0 ? base : tile_end - 1);
-    __syncthreads();
-    const u32 r_lo = tile == 0 ? 0u : s_rows[0];  // tile 0 also owns the empty rows in front of the first non-zero
-    const u32 r_hi = s_rows[1];
+    const u32 k0 = base + t * SP_IPT;
+    const u32 k1 = min(k0 + SP_IPT, tile_end);
+    // the streaming loads and the gathers depend on nothing but k0: in flight before the row structure is looked at
+    u32 c[SP_IPT];
+    float v[SP_IPT], x[SP_IPT];
+    if (k0 + SP_IPT <= nnz) {
+        const uint4 c0 = *reinterpret_cast<const uint4 *>(idx + k0), c1 = *reinterpret_cast<const uint4 *>(idx + k0 + 4);
+        const float4 v0 = *reinterpret_cast<const float4 *>(val + k0), v1 = *reinterpret_cast<const float4 *>(val + k0 + 4);
+        c[0] = c0.x, c[1] = c0.y, c[2] = c0.z, c[3] = c0.w, c[4] = c1.x, c[5] = c1.y, c[6] = c1.z, c[7] = c1.w;
+        v[0] = v0.x, v[1] = v0.y, v[2] = v0.z, v[3] = v0.w, v[4] = v1.x, v[5] = v1.y, v[6] = v1.z, v[7] = v1.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < SP_IPT; ++j) {
+            const bool in = k0 + j < nnz;
+            c[j] = in ? idx[k0 + j] : 0u;
+            v[j] = in ? val[k0 + j] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < SP_IPT; ++j) x[j] = vec[c[j]];  // c is 0 (a valid index) past the end
+
+    const uint2 tr = tile_rows[tile];
+    const u32 r_lo = tr.x, r_hi = tr.y;
     const u32 n_stage = (r_hi - r_lo + 2 <= SP_PTR_LDS) ? r_hi - r_lo + 2 : 0u;  // ptr[r_lo .. r_hi + 1]
     for (u32 i = t; i < n_stage; i += SP_NT) s_ptr[i] = ptr[r_lo + i];
     __syncthreads();
     auto P = [&](u32 r) { return (r - r_lo) < n_stage ? s_ptr[r - r_lo] : ptr[r]; };
 
-    const u32 k0 = base + t * SP_IPT;
-    const u32 k1 = min(k0 + SP_IPT, tile_end);
     double acc = 0.0, first_partial = 0.0;
     u32 first_row = NO_ROW, flushed = 0;
     if (k0 < tile_end) {
-        u32 c[SP_IPT];
-        float v[SP_IPT], x[SP_IPT];
-        if (k0 + SP_IPT <= nnz) {
-            const uint4 c0 = *reinterpret_cast<const uint4 *>(idx + k0), c1 = *reinterpret_cast<const uint4 *>(idx + k0 + 4);
-            const float4 v0 = *reinterpret_cast<const float4 *>(val + k0), v1 = *reinterpret_cast<const float4 *>(val + k0 + 4);
-            c[0] = c0.x, c[1] = c0.y, c[2] = c0.z, c[3] = c0.w, c[4] = c1.x, c[5] = c1.y, c[6] = c1.z, c[7] = c1.w;
-            v[0] = v0.x, v[1] = v0.y, v[2] = v0.z, v[3] = v0.w, v[4] = v1.x, v[5] = v1.y, v[6] = v1.z, v[7] = v1.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < SP_IPT; ++j) {
-                const bool in = k0 + j < nnz;
-                c[j] = in ? idx[k0 + j] : 0u;
-                v[j] = in ? val[k0 + j] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < SP_IPT; ++j) x[j] = vec[c[j]];  // c is 0 (a valid index) for the padding of the last thread
-
         u32 r = (tile == 0 && t == 0) ? 0u : last_row_le(P, r_lo, r_hi, k0);
         u32 end = P(r + 1);
         auto flush = [&]() {
@@ -326,12 +336,14 @@ struct kmers_model {
     float *xval = nullptr, *tval = nullptr, *xtheta = nullptr, *w = nullptr;
     double *ynnz = nullptr, *partials = nullptr, *h_partials = nullptr;
     TileCarry *carry = nullptr;
+    uint2 *xtiles = nullptr, *ttiles = nullptr;  // k_tile_rows of xnnz and of its column-sorted copy
 };
 
 extern "C" void kmers_hip_model_free(kmers_model *m) {
     if (!m) return;
     for (void *p : {(void *)m->rows, (void *)m->xptr, (void *)m->xcol, (void *)m->cptr, (void *)m->trow, (void *)m->xval,
-                    (void *)m->tval, (void *)m->xtheta, (void *)m->w, (void *)m->ynnz, (void *)m->partials, (void *)m->carry})
+                    (void *)m->tval, (void *)m->xtheta, (void *)m->w, (void *)m->ynnz, (void *)m->partials, (void *)m->carry,
+                    (void *)m->xtiles, (void *)m->ttiles})
         if (p) (void)hipFree(p);
     if (m->h_partials) (void)hipHostFree(m->h_partials);
     delete m;
@@ -457,6 +469,12 @@ extern "C" int kmers_hip_model_create(const float *d_data, const uint64_t *d_col
                        m->tval);
     hipLaunchKernelGGL(k_col_ptr, dim3(div_up((u64)m->n_cols + 1, 256)), dim3(256), 0, s, (const u32 *)keys_out.as<u32>(),
                        m->nnz, m->n_cols, m->cptr);
+    MD_CHECK(hipMalloc((void **)&m->xtiles, (size_t)m->n_tiles * sizeof(uint2)));
+    MD_CHECK(hipMalloc((void **)&m->ttiles, (size_t)m->n_tiles * sizeof(uint2)));
+    hipLaunchKernelGGL(k_tile_rows, dim3(div_up(m->n_tiles, 256)), dim3(256), 0, s, (const u32 *)m->xptr, m->n_m, m->nnz,
+                       m->n_tiles, m->xtiles);
+    hipLaunchKernelGGL(k_tile_rows, dim3(div_up(m->n_tiles, 256)), dim3(256), 0, s, (const u32 *)m->cptr, m->n_cols, m->nnz,
+                       m->n_tiles, m->ttiles);
     MD_CHECK(hipGetLastError());
     MD_CHECK(hipStreamSynchronize(s));
     guard.m = nullptr;
@@ -464,15 +482,43 @@ extern "C" int kmers_hip_model_create(const float *d_data, const uint64_t *d_col
     return KMERS_OK;
 }
 
-static int spmv(const kmers_model *m, const u32 *ptr, const u32 *idx, const float *val, const float *vec, u32 n, float *out,
-                hipStream_t s) {
+// Event pairs around the kernels of one logp_grad while kmers_hip_profile_enable is on (read after the sync).
+struct Marks {
+    hipStream_t s;
+    bool on;
+    int n = 0;
+    hipEvent_t ev[8];
+    const char *label[8];
+    explicit Marks(hipStream_t s_) : s(s_), on(kk::profile_on()) { mark(nullptr); }
+    void mark(const char *name) {
+        if (!on || n == 8) return;
+        if (hipEventCreate(&ev[n]) != hipSuccess) {
+            on = false;
+            return;
+        }
+        (void)hipEventRecord(ev[n], s);
+        label[n++] = name;
+    }
+    ~Marks() {  // the stream has been synchronised by then
+        for (int i = 1; i < n; ++i) {
+            float ms = 0.f;
+            if (on && label[i] && hipEventElapsedTime(&ms, ev[i - 1], ev[i]) == hipSuccess) kk::profile_add(label[i], ms);
+        }
+        for (int i = 0; i < n; ++i) (void)hipEventDestroy(ev[i]);
+    }
+};
+
+static int spmv(const kmers_model *m, const u32 *ptr, const u32 *idx, const float *val, const float *vec,
+                const uint2 *tiles, u32 n, float *out, hipStream_t s, Marks &marks, const char *label) {
     if (m->nnz == 0) {
         MD_CHECK(hipMemsetAsync(out, 0, (size_t)n * 4, s));
         return KMERS_OK;
     }
-    hipLaunchKernelGGL(k_spmv, dim3(m->n_tiles), dim3(SP_NT), 0, s, ptr, idx, val, vec, n, m->nnz, out, m->carry);
+    hipLaunchKernelGGL(k_spmv, dim3(m->n_tiles), dim3(SP_NT), 0, s, ptr, idx, val, vec, tiles, n, m->nnz, out, m->carry);
+    marks.mark(label);
     hipLaunchKernelGGL(k_spmv_fixup, dim3(div_up(m->n_tiles, 256)), dim3(256), 0, s, (const TileCarry *)m->carry, m->n_tiles,
                        out);
+    marks.mark("k_spmv_fixup");
     MD_CHECK(hipGetLastError());
     return KMERS_OK;
 }
@@ -481,14 +527,17 @@ extern "C" int kmers_hip_model_logp_grad(kmers_model *m, const float *d_theta, i
                                          void *stream) {
     if (!m || !d_theta || !val_out || (!nograd && !d_grad)) return KMERS_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
-    int rc = spmv(m, m->xptr, m->xcol, m->xval, d_theta, m->n_m, m->xtheta, s);
+    Marks marks(s);
+    int rc = spmv(m, m->xptr, m->xcol, m->xval, d_theta, m->xtiles, m->n_m, m->xtheta, s, marks, "k_spmv<x.theta>");
     if (rc) return rc;
     hipLaunchKernelGGL(k_logp_terms, dim3(TERM_BLOCKS), dim3(256), 0, s, (const float *)m->xtheta, (const double *)m->ynnz,
                        m->n_m, m->w, m->partials);
+    marks.mark("k_logp_terms");
     MD_CHECK(hipGetLastError());
     MD_CHECK(hipMemcpyAsync(m->h_partials, m->partials, TERM_BLOCKS * 8, hipMemcpyDeviceToHost, s));
     if (!nograd) {
-        rc = spmv(m, m->cptr, m->trow, m->tval, m->w, m->n_cols, d_grad, s);
+        marks.mark(nullptr);  // the copy is not a kernel
+        rc = spmv(m, m->cptr, m->trow, m->tval, m->w, m->ttiles, m->n_cols, d_grad, s, marks, "k_spmv<w.x>");
         if (rc) return rc;
     }
     MD_CHECK(hipStreamSynchronize(s));
