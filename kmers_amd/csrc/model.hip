@@ -35,7 +35,10 @@ using u32 = uint32_t;
 using u64 = uint64_t;
 
 constexpr int SP_NT = 256;              // threads per workgroup of k_spmv
-constexpr int SP_IPT = 8;               // consecutive non-zeros per thread
+#ifndef SP_IPT_
+#define SP_IPT_ 8
+#endif
+constexpr int SP_IPT = SP_IPT_;         // consecutive non-zeros per thread (a multiple of 4: 16-byte loads)
 constexpr u32 SP_TILE = SP_NT * SP_IPT; // non-zeros per workgroup
 constexpr u32 SP_PTR_LDS = 4096;        // row pointers of one tile staged in LDS when they fit
 constexpr u32 NO_ROW = 0xFFFFFFFFu;
@@ -96,10 +99,13 @@ __global__ __launch_bounds__(SP_NT) void k_spmv(const u32 *__restrict__ ptr, con
     u32 c[SP_IPT];
     float v[SP_IPT], x[SP_IPT];
     if (k0 + SP_IPT <= nnz) {
-        const uint4 c0 = *reinterpret_cast<const uint4 *>(idx + k0), c1 = *reinterpret_cast<const uint4 *>(idx + k0 + 4);
-        const float4 v0 = *reinterpret_cast<const float4 *>(val + k0), v1 = *reinterpret_cast<const float4 *>(val + k0 + 4);
-        c[0] = c0.x, c[1] = c0.y, c[2] = c0.z, c[3] = c0.w, c[4] = c1.x, c[5] = c1.y, c[6] = c1.z, c[7] = c1.w;
-        v[0] = v0.x, v[1] = v0.y, v[2] = v0.z, v[3] = v0.w, v[4] = v1.x, v[5] = v1.y, v[6] = v1.z, v[7] = v1.w;
+#pragma unroll
+        for (int q = 0; q < SP_IPT / 4; ++q) {
+            const uint4 cq = *reinterpret_cast<const uint4 *>(idx + k0 + 4 * q);
+            const float4 vq = *reinterpret_cast<const float4 *>(val + k0 + 4 * q);
+            c[4 * q] = cq.x, c[4 * q + 1] = cq.y, c[4 * q + 2] = cq.z, c[4 * q + 3] = cq.w;
+            v[4 * q] = vq.x, v[4 * q + 1] = vq.y, v[4 * q + 2] = vq.z, v[4 * q + 3] = vq.w;
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < SP_IPT; ++j) {
@@ -109,7 +115,11 @@ __global__ __launch_bounds__(SP_NT) void k_spmv(const u32 *__restrict__ ptr, con
         }
     }
 #pragma unroll
+#ifdef SP_NOGATHER
+    for (int j = 0; j < SP_IPT; ++j) x[j] = 1.0f + (float)(c[j] & 1);
+#else
     for (int j = 0; j < SP_IPT; ++j) x[j] = vec[c[j]];  // c is 0 (a valid index) past the end
+#endif
 
     const uint2 tr = tile_rows[tile];
     const u32 r_lo = tr.x, r_hi = tr.y;
