@@ -178,6 +178,11 @@ def bench_model(args, K, dev, rank, world, fence):
     avg_ms = dom[1] / dom[2]
     ach = kernel_bytes[dom[0]] / (avg_ms * 1e-3) / 1e9
     path_bytes = sum(kernel_bytes.values())
+    traffic = None            # measured by rocprofv3 PMC passes of this same command (tools/pmc.sh + tools/pmc_traffic.py)
+    tpath = os.path.join(ROOT, "kmers_amd", "data", "pmc_traffic.json")
+    if (args.records, args.bases, args.reads) == (170_000, 400_000_000, 10_000_000) and os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get(args.workload, {}).get("kernels", {}).get(dom[0], {}).get("bytes")
     out = {
         "metric": "logp_grad non-zeros/s (X.theta + X^T.(y/X.theta) on the resident X; SURVEY.md 8f row 4)",
         "value": 2 * nnz * world * args.steps / dt, "unit": "non-zeros/s", "n_gpus": world, "steps": args.steps,
@@ -188,7 +193,7 @@ def bench_model(args, K, dev, rank, world, fence):
                    "K": K, "nnz_x": nnz_x, "masked_rows": n_m, "nnz_xnnz": nnz, "val": val,
                    "model_setup_s": round(setup_s, 3), "parallelism": f"replicas{world}"},
         "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(avg_ms, 4),
+                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_ms": round(avg_ms, 4),
                      "launches_per_step": dom[2] // max(args.steps, 1), "algorithmic_bytes": int(kernel_bytes[dom[0]])},
         "path": {"algorithmic_bytes": int(path_bytes),
                  "achieved_GBs": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 1)},

@@ -23,6 +23,7 @@
 #include "kernels.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>  // before rocprim: one of its iterator headers calls memset without including this
 #include <new>
 
@@ -83,10 +84,12 @@ __global__ __launch_bounds__(256) void k_tile_rows(const u32 *__restrict__ ptr, 
 }
 
 // out[r] = sum_{k in [ptr[r], ptr[r+1])} val[k] * vec[idx[k]]     for r < n;  ptr[n] == nnz > 0
+// WHICH only names the instantiation in profiles: 0 = xnnz . theta, 1 = w . xnnz (on the column-sorted copy)
+template <int WHICH, class OutT>
 __global__ __launch_bounds__(SP_NT) void k_spmv(const u32 *__restrict__ ptr, const u32 *__restrict__ idx,
                                                 const float *__restrict__ val, const float *__restrict__ vec,
                                                 const uint2 *__restrict__ tile_rows, u32 n, u32 nnz,
-                                                float *__restrict__ out, TileCarry *__restrict__ carry) {
+                                                OutT *__restrict__ out, TileCarry *__restrict__ carry) {
     __shared__ u32 s_ptr[SP_PTR_LDS];
     __shared__ double s_wave_a[SP_NT / 64];
     __shared__ u32 s_wave_f[SP_NT / 64];
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(SP_NT) void k_spmv(const u32 *__restrict__ ptr, con
                 first_partial = acc;
                 flushed = 1;
             } else {
-                out[r] = (float)acc;
+                out[r] = (OutT)acc;
             }
             acc = 0.0;
         };
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(SP_NT) void k_spmv(const u32 *__restrict__ ptr, con
     if (flushed) {
         const double vsum = first_partial + carry_in;
         if (head_open && first_row == r_lo) carry[tile].head_partial = vsum;
-        else out[first_row] = (float)vsum;
+        else out[first_row] = (OutT)vsum;
     }
     if (t == SP_NT - 1) {
         // inclusive value of the last thread == fold over the whole tile
@@ -210,7 +213,8 @@ __global__ __launch_bounds__(SP_NT) void k_spmv(const u32 *__restrict__ ptr, con
 }
 
 // rows that span tiles: add the tails of the tiles in front, nearest first, back to the tile the row started in
-__global__ void k_spmv_fixup(const TileCarry *__restrict__ carry, u32 n_tiles, float *__restrict__ out) {
+template <class OutT>
+__global__ void k_spmv_fixup(const TileCarry *__restrict__ carry, u32 n_tiles, OutT *__restrict__ out) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_tiles || i == 0) return;
     const u32 row = carry[i].head_row;
@@ -220,7 +224,17 @@ __global__ void k_spmv_fixup(const TileCarry *__restrict__ carry, u32 n_tiles, f
         s += carry[j].tail;
         if (carry[j].flushed) break;
     }
-    out[row] = (float)s;
+    out[row] = (OutT)s;
+}
+
+// grad[c] = sum over the row slabs of part[slab][c], in slab order
+__global__ __launch_bounds__(256) void k_reduce_slabs(const double *__restrict__ part, u32 n_slabs, u32 n_cols,
+                                                      float *__restrict__ grad) {
+    const u32 c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cols) return;
+    double s = 0.0;
+    for (u32 b = 0; b < n_slabs; ++b) s += part[(size_t)b * n_cols + c];
+    grad[c] = (float)s;
 }
 
 // val partials and w = ynnz / xtheta (float64 / float32 -> float32, as utils.py:102 stores it)
@@ -279,19 +293,23 @@ __global__ __launch_bounds__(256) void k_row_lens(const u32 *__restrict__ rows, 
     if (threadIdx.x == 0) atomicAdd(stats + 1, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
 
-// non-zero k of xnnz <- X: column narrowed to 32 bits, (masked row, value bits) packed as the sort's payload
+// non-zero k of xnnz <- X: column narrowed to 32 bits; for the sort of the transposed copy the key
+// (row slab, column) and the payload (masked row, value bits)
 __global__ __launch_bounds__(256) void k_gather_rows(const u32 *__restrict__ xptr, const u32 *__restrict__ rows, u32 n_m,
                                                      u32 nnz, const u64 *__restrict__ row_ind, const u64 *__restrict__ col_ind,
-                                                     const float *__restrict__ data, u32 *__restrict__ xcol,
-                                                     float *__restrict__ xval, u64 *__restrict__ payload) {
+                                                     const float *__restrict__ data, u32 slab_shift, u32 n_cols,
+                                                     u32 *__restrict__ xcol, float *__restrict__ xval,
+                                                     u32 *__restrict__ keys, u64 *__restrict__ payload) {
     const u32 k = blockIdx.x * 256 + threadIdx.x;
     if (k >= nnz) return;
     auto P = [&](u32 r) { return xptr[r]; };
     const u32 i = last_row_le(P, 0u, n_m - 1, k);
     const u64 src = row_ind[rows[i]] + (k - xptr[i]);
     const float v = data[src];
-    xcol[k] = (u32)col_ind[src];
+    const u32 col = (u32)col_ind[src];
+    xcol[k] = col;
     xval[k] = v;
+    keys[k] = (i >> slab_shift) * n_cols + col;
     payload[k] = ((u64)i << 32) | __float_as_uint(v);
 }
 
@@ -341,11 +359,13 @@ struct kmers_model {
     int device = 0;
     u64 n_rows = 0;
     u32 n_cols = 0, n_m = 0, nnz = 0, n_tiles = 0;
+    u32 slab_shift = 31, n_slabs = 1, n_trows = 0;  // transposed copy: n_slabs row slabs x n_cols columns = n_trows rows
     long long sum_y = 0;
     u32 *rows = nullptr, *xptr = nullptr, *xcol = nullptr, *cptr = nullptr, *trow = nullptr;
     float *xval = nullptr, *tval = nullptr, *xtheta = nullptr, *w = nullptr;
     double *ynnz = nullptr, *partials = nullptr, *h_partials = nullptr;
     TileCarry *carry = nullptr;
+    double *gpart = nullptr;  // n_slabs > 1: per-slab partial gradients
     uint2 *xtiles = nullptr, *ttiles = nullptr;  // k_tile_rows of xnnz and of its column-sorted copy
 };
 
@@ -353,7 +373,7 @@ extern "C" void kmers_hip_model_free(kmers_model *m) {
     if (!m) return;
     for (void *p : {(void *)m->rows, (void *)m->xptr, (void *)m->xcol, (void *)m->cptr, (void *)m->trow, (void *)m->xval,
                     (void *)m->tval, (void *)m->xtheta, (void *)m->w, (void *)m->ynnz, (void *)m->partials, (void *)m->carry,
-                    (void *)m->xtiles, (void *)m->ttiles})
+                    (void *)m->xtiles, (void *)m->ttiles, (void *)m->gpart})
         if (p) (void)hipFree(p);
     if (m->h_partials) (void)hipHostFree(m->h_partials);
     delete m;
@@ -444,14 +464,30 @@ extern "C" int kmers_hip_model_create(const float *d_data, const uint64_t *d_col
     MD_CHECK(hipMalloc((void **)&m->partials, TERM_BLOCKS * 8));
     MD_CHECK(hipHostMalloc((void **)&m->h_partials, TERM_BLOCKS * 8, hipHostMallocDefault));
     MD_CHECK(hipMalloc((void **)&m->carry, ((size_t)m->n_tiles + 1) * sizeof(TileCarry)));
-    MD_CHECK(hipMalloc((void **)&m->cptr, ((size_t)m->n_cols + 1) * 4));
+    // Row slabs of the transposed copy: the transposed product gathers w[row]; with more masked rows than an L2 holds
+    // (K >= 11 or so) every gather would be an HBM access of its own (measured at K=14: 128 bytes fetched per
+    // non-zero, 5.1 ms).  Sorting by (row slab, column) with 2 MB of w per slab keeps the gathers of one tile in L2;
+    // the product then yields one partial gradient per slab, added up in slab order by k_reduce_slabs.
+    {
+        u32 shift = 19;  // 2^19 rows = 2 MB of w: half of one XCD's L2
+        if (const char *e = getenv("KMERS_MODEL_SLAB_LOG2")) shift = (u32)atoi(e);
+        if (shift < 8) shift = 8;
+        if (shift > 31) shift = 31;
+        while (shift < 31 && (u64)div_up(m->n_m, 1u << shift) * m->n_cols >= 0xFFFFFFF0ull) ++shift;
+        m->slab_shift = shift;
+        m->n_slabs = div_up(m->n_m, 1u << shift);
+        if ((u64)m->n_slabs * m->n_cols >= 0xFFFFFFF0ull) return KMERS_ERR_TOO_LARGE;
+        m->n_trows = m->n_slabs * m->n_cols;
+    }
+    if (m->n_slabs > 1) MD_CHECK(hipMalloc((void **)&m->gpart, (size_t)m->n_trows * 8));
+    MD_CHECK(hipMalloc((void **)&m->cptr, ((size_t)m->n_trows + 1) * 4));
     const size_t nz = m->nnz ? m->nnz : 1;
     MD_CHECK(hipMalloc((void **)&m->xcol, nz * 4 + 64));
     MD_CHECK(hipMalloc((void **)&m->xval, nz * 4 + 64));
     MD_CHECK(hipMalloc((void **)&m->trow, nz * 4 + 64));
     MD_CHECK(hipMalloc((void **)&m->tval, nz * 4 + 64));
     if (m->nnz == 0) {
-        MD_CHECK(hipMemsetAsync(m->cptr, 0, ((size_t)m->n_cols + 1) * 4, s));
+        MD_CHECK(hipMemsetAsync(m->cptr, 0, ((size_t)m->n_trows + 1) * 4, s));
         MD_CHECK(hipStreamSynchronize(s));
         guard.m = nullptr;
         *out = m;
@@ -460,30 +496,32 @@ extern "C" int kmers_hip_model_create(const float *d_data, const uint64_t *d_col
     if (!d_data || !d_col_ind) return KMERS_ERR_BAD_ARG;
 
     // 4. xnnz = x[ymask], and its copy sorted by column (stable: rows ascend inside a column)
-    Dev pay_in, pay_out, keys_out, t3;
+    Dev pay_in, pay_out, keys_in, keys_out, t3;
     MD_CHECK(pay_in.alloc(nz * 8));
     MD_CHECK(pay_out.alloc(nz * 8));
+    MD_CHECK(keys_in.alloc(nz * 4));
     MD_CHECK(keys_out.alloc(nz * 4));
     hipLaunchKernelGGL(k_gather_rows, dim3(div_up(m->nnz, 256)), dim3(256), 0, s, (const u32 *)m->xptr, (const u32 *)m->rows,
-                       m->n_m, m->nnz, d_row_ind, d_col_ind, d_data, m->xcol, m->xval, pay_in.as<u64>());
+                       m->n_m, m->nnz, d_row_ind, d_col_ind, d_data, m->slab_shift, m->n_cols, m->xcol, m->xval, keys_in.as<u32>(),
+                       pay_in.as<u64>());
     MD_CHECK(hipGetLastError());
     unsigned bits = 1;
-    while (bits < 32 && (1ull << bits) < n_cols) ++bits;
+    while (bits < 32 && (1ull << bits) < m->n_trows) ++bits;
     size_t sb = 0;
-    MD_CHECK(rocprim::radix_sort_pairs(nullptr, sb, (const u32 *)m->xcol, keys_out.as<u32>(), (const u64 *)pay_in.as<u64>(),
+    MD_CHECK(rocprim::radix_sort_pairs(nullptr, sb, (const u32 *)keys_in.as<u32>(), keys_out.as<u32>(), (const u64 *)pay_in.as<u64>(),
                                        pay_out.as<u64>(), (size_t)m->nnz, 0u, bits, s));
     MD_CHECK(t3.alloc(sb));
-    MD_CHECK(rocprim::radix_sort_pairs(t3.p, sb, (const u32 *)m->xcol, keys_out.as<u32>(), (const u64 *)pay_in.as<u64>(),
+    MD_CHECK(rocprim::radix_sort_pairs(t3.p, sb, (const u32 *)keys_in.as<u32>(), keys_out.as<u32>(), (const u64 *)pay_in.as<u64>(),
                                        pay_out.as<u64>(), (size_t)m->nnz, 0u, bits, s));
     hipLaunchKernelGGL(k_unpack, dim3(div_up(m->nnz, 256)), dim3(256), 0, s, (const u64 *)pay_out.as<u64>(), m->nnz, m->trow,
                        m->tval);
-    hipLaunchKernelGGL(k_col_ptr, dim3(div_up((u64)m->n_cols + 1, 256)), dim3(256), 0, s, (const u32 *)keys_out.as<u32>(),
-                       m->nnz, m->n_cols, m->cptr);
+    hipLaunchKernelGGL(k_col_ptr, dim3(div_up((u64)m->n_trows + 1, 256)), dim3(256), 0, s, (const u32 *)keys_out.as<u32>(),
+                       m->nnz, m->n_trows, m->cptr);
     MD_CHECK(hipMalloc((void **)&m->xtiles, (size_t)m->n_tiles * sizeof(uint2)));
     MD_CHECK(hipMalloc((void **)&m->ttiles, (size_t)m->n_tiles * sizeof(uint2)));
     hipLaunchKernelGGL(k_tile_rows, dim3(div_up(m->n_tiles, 256)), dim3(256), 0, s, (const u32 *)m->xptr, m->n_m, m->nnz,
                        m->n_tiles, m->xtiles);
-    hipLaunchKernelGGL(k_tile_rows, dim3(div_up(m->n_tiles, 256)), dim3(256), 0, s, (const u32 *)m->cptr, m->n_cols, m->nnz,
+    hipLaunchKernelGGL(k_tile_rows, dim3(div_up(m->n_tiles, 256)), dim3(256), 0, s, (const u32 *)m->cptr, m->n_trows, m->nnz,
                        m->n_tiles, m->ttiles);
     MD_CHECK(hipGetLastError());
     MD_CHECK(hipStreamSynchronize(s));
@@ -497,11 +535,11 @@ struct Marks {
     hipStream_t s;
     bool on;
     int n = 0;
-    hipEvent_t ev[8];
-    const char *label[8];
+    hipEvent_t ev[12];
+    const char *label[12];
     explicit Marks(hipStream_t s_) : s(s_), on(kk::profile_on()) { mark(nullptr); }
     void mark(const char *name) {
-        if (!on || n == 8) return;
+        if (!on || n == 12) return;
         if (hipEventCreate(&ev[n]) != hipSuccess) {
             on = false;
             return;
@@ -518,15 +556,16 @@ struct Marks {
     }
 };
 
+template <int WHICH, class OutT>
 static int spmv(const kmers_model *m, const u32 *ptr, const u32 *idx, const float *val, const float *vec,
-                const uint2 *tiles, u32 n, float *out, hipStream_t s, Marks &marks, const char *label) {
+                const uint2 *tiles, u32 n, OutT *out, hipStream_t s, Marks &marks, const char *label) {
     if (m->nnz == 0) {
-        MD_CHECK(hipMemsetAsync(out, 0, (size_t)n * 4, s));
+        MD_CHECK(hipMemsetAsync(out, 0, (size_t)n * sizeof(OutT), s));
         return KMERS_OK;
     }
-    hipLaunchKernelGGL(k_spmv, dim3(m->n_tiles), dim3(SP_NT), 0, s, ptr, idx, val, vec, tiles, n, m->nnz, out, m->carry);
+    hipLaunchKernelGGL((k_spmv<WHICH, OutT>), dim3(m->n_tiles), dim3(SP_NT), 0, s, ptr, idx, val, vec, tiles, n, m->nnz, out, m->carry);
     marks.mark(label);
-    hipLaunchKernelGGL(k_spmv_fixup, dim3(div_up(m->n_tiles, 256)), dim3(256), 0, s, (const TileCarry *)m->carry, m->n_tiles,
+    hipLaunchKernelGGL(k_spmv_fixup<OutT>, dim3(div_up(m->n_tiles, 256)), dim3(256), 0, s, (const TileCarry *)m->carry, m->n_tiles,
                        out);
     marks.mark("k_spmv_fixup");
     MD_CHECK(hipGetLastError());
@@ -538,7 +577,7 @@ extern "C" int kmers_hip_model_logp_grad(kmers_model *m, const float *d_theta, i
     if (!m || !d_theta || !val_out || (!nograd && !d_grad)) return KMERS_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     Marks marks(s);
-    int rc = spmv(m, m->xptr, m->xcol, m->xval, d_theta, m->xtiles, m->n_m, m->xtheta, s, marks, "k_spmv<x.theta>");
+    int rc = spmv<0>(m, m->xptr, m->xcol, m->xval, d_theta, m->xtiles, m->n_m, m->xtheta, s, marks, "k_spmv<x.theta>");
     if (rc) return rc;
     hipLaunchKernelGGL(k_logp_terms, dim3(TERM_BLOCKS), dim3(256), 0, s, (const float *)m->xtheta, (const double *)m->ynnz,
                        m->n_m, m->w, m->partials);
@@ -547,8 +586,17 @@ extern "C" int kmers_hip_model_logp_grad(kmers_model *m, const float *d_theta, i
     MD_CHECK(hipMemcpyAsync(m->h_partials, m->partials, TERM_BLOCKS * 8, hipMemcpyDeviceToHost, s));
     if (!nograd) {
         marks.mark(nullptr);  // the copy is not a kernel
-        rc = spmv(m, m->cptr, m->trow, m->tval, m->w, m->ttiles, m->n_cols, d_grad, s, marks, "k_spmv<w.x>");
-        if (rc) return rc;
+        if (m->n_slabs == 1) {
+            rc = spmv<1>(m, m->cptr, m->trow, m->tval, m->w, m->ttiles, m->n_cols, d_grad, s, marks, "k_spmv<w.x>");
+            if (rc) return rc;
+        } else {
+            rc = spmv<1>(m, m->cptr, m->trow, m->tval, m->w, m->ttiles, m->n_trows, m->gpart, s, marks, "k_spmv<w.x>");
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_reduce_slabs, dim3(div_up(m->n_cols, 256)), dim3(256), 0, s, (const double *)m->gpart,
+                               m->n_slabs, m->n_cols, d_grad);
+            marks.mark("k_reduce_slabs");
+            MD_CHECK(hipGetLastError());
+        }
     }
     MD_CHECK(hipStreamSynchronize(s));
     double v = 0.0;

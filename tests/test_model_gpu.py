@@ -80,6 +80,24 @@ def test_logp_grad_vs_oracle(syn, K):
         check(model, x, y, theta)
 
 
+@pytest.mark.parametrize("K,slab_log2", [(6, 8), (11, 8), (14, 12), (14, 16)])
+def test_row_slabs_of_the_transposed_copy(syn, K, slab_log2, monkeypatch):
+    """With more masked rows than an L2 holds the transposed copy is sorted by (row slab, column) and the gradient is
+    the sum of per-slab partials; KMERS_MODEL_SLAB_LOG2 forces small slabs (2^8 rows: hundreds of slabs) here."""
+    from kmers_amd.multinomial_simplex_model import multinomial_simplex_model
+    x, y = xy(syn, K)
+    monkeypatch.setenv("KMERS_MODEL_SLAB_LOG2", str(slab_log2))
+    model = multinomial_simplex_model(x, y)
+    assert model.device_model.n_masked > 4 << slab_log2
+    monkeypatch.setenv("KMERS_MODEL_SLAB_LOG2", "31")
+    whole = multinomial_simplex_model(x, y)
+    for theta in thetas(model.T, K):
+        val, grad = check(model, x, y, theta)
+        val1, grad1 = whole.logp_grad(theta)
+        assert val1 == val
+        np.testing.assert_allclose(grad, grad1, rtol=2e-7, atol=1e-30)   # float64 partials: one float32 rounding apart
+
+
 def test_beta_terms_and_lengths(syn):
     from kmers_amd.multinomial_simplex_model import multinomial_simplex_model
     x, y = xy(syn, 7)

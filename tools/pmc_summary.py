@@ -14,7 +14,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
             name = r["Kernel_Name"].split("(")[0]
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(acc):
-    if not k.startswith("kk::") and "kk::" not in k:
+    if "kk::" not in k and "k_spmv" not in k and "k_logp_terms" not in k:
         continue
     print(k)
     for c in sorted(acc[k]):

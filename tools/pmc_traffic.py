@@ -15,6 +15,9 @@ from collections import defaultdict
 
 root, workload = sys.argv[1], sys.argv[2]
 LABEL = [  # kernel symbol (regex) -> the label of bench.py's per-kernel table
+    (r"k_spmv<0", "k_spmv<x.theta>"),
+    (r"k_spmv<1", "k_spmv<w.x>"),
+    (r"k_logp_terms", "k_logp_terms"),
     (r"k_rle<", "k_rle"),
     (r"k_scatter<true, unsigned int, true|k_yscatter", "k_scatter<bases,y>"),
     (r"k_scatter<true", "k_scatter<bases>"),
