@@ -149,8 +149,9 @@ int kmers_npz_write_csr(const char *path, const float *data, const uint64_t *col
 /* ---- the step after the path: logp_grad's two sparse products on the resident X ---- */
 
 /* Device-side state of the reference's multinomial_simplex_model (kmerexpr/multinomial_simplex_model.py:56-62):
- * ymask = y.nonzero(), xnnz = x[ymask] (a CSR with 32-bit indices, plus a copy sorted by column for the transposed
- * product), ynnz = y[ymask] / sum(y) (float64).  Everything lives in HBM until kmers_hip_model_free. */
+ * ymask = y.nonzero(), xnnz = x[ymask] (a CSR with 32-bit indices, plus a transposed copy sorted by (row slab,
+ * column) for the transposed product; KMERS_MODEL_SLAB_LOG2 overrides the 2^19 rows per slab),
+ * ynnz = y[ymask] / sum(y) (float64).  Everything lives in HBM until kmers_hip_model_free. */
 typedef struct kmers_model kmers_model;
 
 /* Build the model from X as kmers_hip_build_x left it in HBM (d_data f32[nnz], d_col_ind u64[nnz],

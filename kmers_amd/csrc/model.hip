@@ -9,9 +9,10 @@
 // arithmetic on the caller's theta and stay with the caller (kmers_amd/multinomial_simplex_model.py).
 //
 // Layout.  xnnz is a CSR with 4-byte row pointers, 4-byte columns and float32 values (8 bytes per non-zero instead of
-// the ABI's 12); a second copy sorted by column (cptr / trow / tval) serves the transposed product, so both products
-// are the same gather kernel and neither needs float atomics: results are deterministic.  The copy is made once
-// per model with rocPRIM's stable radix sort (a set-up step, not the hot loop).
+// the ABI's 12); a second, transposed copy (cptr / trow / tval) serves the transposed product, so both products are
+// the same gather kernel and neither needs float atomics: results are deterministic.  The transposed copy is sorted
+// by (row slab, column), 2 MB of w per slab, so that its gathers stay in L2 when there are millions of masked rows;
+// it is made once per model with rocPRIM's stable radix sort (a set-up step, not the hot loop).
 //
 // k_spmv splits the NON-ZEROS evenly (2048 per workgroup, 8 consecutive ones per thread), whatever the row lengths
 // are (K=8: ~4000 per row; K=14: 1-2 per row, many empty rows): a thread walks its 8 products along the row
