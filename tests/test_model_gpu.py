@@ -173,6 +173,39 @@ def test_device_resident_route(syn):
     np.testing.assert_allclose(grad.cpu().numpy(), want_grad, rtol=1e-6, atol=1e-30)
 
 
+def test_k15_device_route(syn):
+    """K=15, the reference drivers' own setting (run_single.py): 2^30 rows, X and y built and kept on the device, the
+    model made from the device buffers; the oracle works on the downloaded arrays."""
+    import torch
+    from kmers_amd.model import DeviceModel
+    from kmers_amd.store import MODE_X, MODE_Y_FASTA, Store
+    K = 15
+    xs = Store(syn["iso"], MODE_X).to_device()
+    buf = xs.x_buffers(K, xs.n_pos)
+    nnz = xs.build_x(buf)
+    buf["workspace"] = None
+    counts = Store(syn["reads"], MODE_Y_FASTA).to_device().count_y(K)
+    T = xs.n_rec_total
+    dm = DeviceModel(buf["data"], buf["col_ind"], buf["row_ind"], T, counts)
+    y = counts.cpu().numpy()
+    rows = np.flatnonzero(y)
+    assert np.array_equal(dm.rows(), rows) and dm.sum_y == int(y.sum(dtype=np.int64))
+    row_ind = buf["row_ind"].cpu().numpy()
+    data, col = buf["data"][:nnz].cpu().numpy(), buf["col_ind"][:nnz].cpu().numpy()
+    lens = row_ind[rows + 1] - row_ind[rows]
+    indptr = np.concatenate([[0], np.cumsum(lens)])
+    take = np.repeat(row_ind[rows] - indptr[:-1], lens) + np.arange(indptr[-1])
+    xnnz = csr_matrix((data[take].astype(np.float64), col[take], indptr), shape=(rows.shape[0], T))
+    assert dm.nnz == xnnz.nnz
+    ynnz = y[rows] / y.sum(dtype=np.int64)
+    theta = np.random.default_rng(7).dirichlet(np.full(T, 0.5)).astype(np.float32)
+    want_val, want_grad, want_xt = orc.logp_grad_ref(theta, 1.0, xnnz, ynnz, np.ones(T))
+    val, grad = dm.logp_grad(torch.from_numpy(theta).cuda())
+    np.testing.assert_allclose(dm.xtheta(), want_xt, rtol=2e-7, atol=1e-45)
+    np.testing.assert_allclose(val, want_val, atol=5e-7)
+    np.testing.assert_allclose(grad.cpu().numpy(), want_grad, rtol=1e-6, atol=1e-30)
+
+
 def test_all_zero_y_is_rejected(syn):
     from kmers_amd.multinomial_simplex_model import multinomial_simplex_model
     x, y = xy(syn, 4)
