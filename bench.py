@@ -9,7 +9,8 @@ A step = one pass of the hot path over one batch of synthetic input that is alre
   x14 configs[2]: the same transcriptome at K=14
   y12 configs[3] per-GPU share: simulated 100 bp reads -> dense int32 histogram at K=12 (kmers_hip_count_y)
   g8, g14 (not a BASELINE.json config): one logp_grad evaluation (X.theta, the log-likelihood
-      term and X^T.(y / X.theta)) on the X and y of the configs above, resident in HBM; unit non-zeros/s; replicas only
+      term and X^T.(y / X.theta)) on the X and y of the configs above, resident in HBM; unit non-zeros/s; for N > 1 every
+      rank holds its own isoforms as a column shard of X, y and X.theta are all-reduced (kmers_amd.distributed.ShardedModel)
 For N > 1 (one process per GPU, torchrun) every rank works on its own shard of the same shape (weak scaling: X column
 shards need no collective; y shards are summed with one RCCL all-reduce inside the timed step).
 Rank 0 prints ONE JSON line.  `value` is k-mers/s over all ranks, a k-mer being one window position
@@ -128,8 +129,8 @@ def cpu_baseline(args, K, kind_x):
 
 
 def bench_model(args, K, dev, rank, world, fence):
-    """g<K>: logp_grad on the resident X and y (kmers_hip_model_*).  Every rank runs the same evaluation on its own
-    shard-shaped inputs (replicas only: the fit's theta is global, sharding it is the solver's business)."""
+    """g<K>: logp_grad on the resident X and y (kmers_hip_model_*).  N > 1: weak scaling over column shards -- every
+    rank's transcriptome is its shard of the columns, the histogram and X.theta are all-reduced."""
     import torch
     from kmers_amd import _lib
     from kmers_amd.model import DeviceModel
@@ -142,6 +143,9 @@ def bench_model(args, K, dev, rank, world, fence):
     buf["workspace"] = None
     ys = Store(reads, MODE_Y_FASTA)
     counts = ys.to_device(dev).count_y(K)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(counts)              # every rank masks the same rows: y of all ranks' reads
     torch.cuda.synchronize()
     T = xs.n_rec_total
     t0 = time.perf_counter()
@@ -150,9 +154,16 @@ def bench_model(args, K, dev, rank, world, fence):
     theta = torch.full((T,), 1.0 / T, dtype=torch.float32, device=dev)
     val = 0.0
 
+    xtheta = torch.empty(dm.n_masked, dtype=torch.float32, device=dev)
+
     def step():
         nonlocal val
-        val, _ = dm.logp_grad(theta)
+        if world == 1:
+            val, _ = dm.logp_grad(theta)
+        else:                                # column shards: this rank's isoforms are its columns of X
+            dm.xtheta_into(theta, xtheta)
+            dist.all_reduce(xtheta)          # RCCL: float32[masked rows], the evaluation's one exchange step
+            val, _ = dm.grad_from(xtheta)
 
     for _ in range(args.warmup):
         step()
@@ -165,6 +176,14 @@ def bench_model(args, K, dev, rank, world, fence):
     dt = time.perf_counter() - t0
     table = _lib.profile_table()
     _lib.profile(False)
+    if world > 1:
+        t = torch.tensor([dt, float(dm.nnz)], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, nnz_all = float(tmax[0].item()), float(t[1].item())
+    else:
+        nnz_all = float(dm.nnz)
     if rank != 0:
         return
     ms_per_step = dt / args.steps * 1e3
@@ -185,13 +204,13 @@ def bench_model(args, K, dev, rank, world, fence):
             traffic = json.load(f).get(args.workload, {}).get("kernels", {}).get(dom[0], {}).get("bytes")
     out = {
         "metric": "logp_grad non-zeros/s (X.theta + X^T.(y/X.theta) on the resident X; SURVEY.md 8f row 4)",
-        "value": 2 * nnz * world * args.steps / dt, "unit": "non-zeros/s", "n_gpus": world, "steps": args.steps,
+        "value": 2 * nnz_all * args.steps / dt, "unit": "non-zeros/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 in, f64 accumulate", "data": "synthetic",
         "config": {"workload": f"logp_grad K={K}: X of {T} isoforms / {xs.n_bases / 1e6:.0f} Mbases, y of {args.reads} "
-                               f"simulated 100 bp reads ({args.workload}; replicas only)",
+                               f"simulated 100 bp reads per GPU ({args.workload}; column shards, xtheta all-reduced)",
                    "K": K, "nnz_x": nnz_x, "masked_rows": n_m, "nnz_xnnz": nnz, "val": val,
-                   "model_setup_s": round(setup_s, 3), "parallelism": f"replicas{world}"},
+                   "model_setup_s": round(setup_s, 3), "parallelism": f"column-shards{world}"},
         "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_ms": round(avg_ms, 4),
                      "launches_per_step": dom[2] // max(args.steps, 1), "algorithmic_bytes": int(kernel_bytes[dom[0]])},
@@ -227,6 +246,9 @@ def bench_model(args, K, dev, rank, world, fence):
 
 def main():
     args = parse()
+    if os.environ.get("KMERS_BENCH_WATCHDOG"):     # seconds: dump every thread's stack and exit instead of hanging
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["KMERS_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

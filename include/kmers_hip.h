@@ -162,6 +162,14 @@ typedef struct kmers_model kmers_model;
 int kmers_hip_model_create(const float *d_data, const uint64_t *d_col_ind, const uint64_t *d_row_ind, uint64_t n_rows,
                            uint64_t n_cols, const int32_t *d_y, void *stream, kmers_model **out);
 void kmers_hip_model_free(kmers_model *m);
+
+/* The same for one column shard of X (multi-GPU fit, one process per GPU): this GPU's X holds the columns
+ * [first_col, first_col + n_cols) under their global numbers, as kmers_hip_build_x writes them for a shard; d_y is
+ * the histogram of ALL reads (after the all-reduce), so every rank masks the same rows.  theta and grad of this
+ * model are the shard's n_cols entries. */
+int kmers_hip_model_create_shard(const float *d_data, const uint64_t *d_col_ind, const uint64_t *d_row_ind,
+                                 uint64_t n_rows, uint64_t first_col, uint64_t n_cols, const int32_t *d_y, void *stream,
+                                 kmers_model **out);
 uint64_t kmers_hip_model_n_masked(const kmers_model *m);   /* rows of xnnz = number of non-zeros of y          */
 uint64_t kmers_hip_model_nnz(const kmers_model *m);        /* non-zeros of xnnz                                */
 int64_t kmers_hip_model_sum_y(const kmers_model *m);       /* the reference's self.N                           */
@@ -179,6 +187,14 @@ int kmers_hip_model_read(const kmers_model *m, int what, void *host_dst);
  * :104-106) are O(n_cols) arithmetic on the caller's theta and are not computed here.
  * Synchronises `stream` (val is read back).  Calls on one model must not overlap. */
 int kmers_hip_model_logp_grad(kmers_model *m, const float *d_theta, int nograd, double *val_out, float *d_grad,
+                              void *stream);
+
+/* logp_grad in two steps, for column shards: d_xtheta f32[n_masked] (caller's buffer) = this shard's xnnz.theta
+ * (asynchronous); the caller sums the shards' buffers (one all-reduce over RCCL: the path's only exchange step);
+ * then val, and this shard's gradient entries, from the summed xtheta (synchronises `stream`).
+ * kmers_hip_model_logp_grad is the two steps on the model's own buffer. */
+int kmers_hip_model_xtheta_into(kmers_model *m, const float *d_theta, float *d_xtheta, void *stream);
+int kmers_hip_model_grad_from(kmers_model *m, const float *d_xtheta, int nograd, double *val_out, float *d_grad,
                               void *stream);
 
 #ifdef __cplusplus

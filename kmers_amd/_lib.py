@@ -93,6 +93,12 @@ def handle():
     lib.kmers_npz_write_csr.argtypes = [C.c_char_p, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64]
     lib.kmers_hip_model_create.restype = C.c_int
     lib.kmers_hip_model_create.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp, C.POINTER(vp)]
+    lib.kmers_hip_model_create_shard.restype = C.c_int
+    lib.kmers_hip_model_create_shard.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, vp, vp, C.POINTER(vp)]
+    lib.kmers_hip_model_xtheta_into.restype = C.c_int
+    lib.kmers_hip_model_xtheta_into.argtypes = [vp, vp, vp, vp]
+    lib.kmers_hip_model_grad_from.restype = C.c_int
+    lib.kmers_hip_model_grad_from.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_double), vp, vp]
     lib.kmers_hip_model_free.restype, lib.kmers_hip_model_free.argtypes = None, [vp]
     for name in ("n_masked", "nnz"):
         f = getattr(lib, "kmers_hip_model_" + name)

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_row_lens(const u32 *__restrict__ rows, 
 // (row slab, column) and the payload (masked row, value bits)
 __global__ __launch_bounds__(256) void k_gather_rows(const u32 *__restrict__ xptr, const u32 *__restrict__ rows, u32 n_m,
                                                      u32 nnz, const u64 *__restrict__ row_ind, const u64 *__restrict__ col_ind,
-                                                     const float *__restrict__ data, u32 slab_shift, u32 n_cols,
+                                                     const float *__restrict__ data, u64 first_col, u32 slab_shift, u32 n_cols,
                                                      u32 *__restrict__ xcol, float *__restrict__ xval,
                                                      u32 *__restrict__ keys, u64 *__restrict__ payload) {
     const u32 k = blockIdx.x * 256 + threadIdx.x;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const u32 *__restrict__ xpt
     const u32 i = last_row_le(P, 0u, n_m - 1, k);
     const u64 src = row_ind[rows[i]] + (k - xptr[i]);
     const float v = data[src];
-    const u32 col = (u32)col_ind[src];
+    const u32 col = (u32)(col_ind[src] - first_col);  // the host checked nothing: a shard's columns are its own range
     xcol[k] = col;
     xval[k] = v;
     keys[k] = (i >> slab_shift) * n_cols + col;
@@ -393,9 +393,9 @@ extern "C" int kmers_hip_model_read(const kmers_model *m, int what, void *host_d
     return KMERS_OK;
 }
 
-extern "C" int kmers_hip_model_create(const float *d_data, const uint64_t *d_col_ind, const uint64_t *d_row_ind,
-                                      uint64_t n_rows, uint64_t n_cols, const int32_t *d_y, void *stream,
-                                      kmers_model **out) {
+extern "C" int kmers_hip_model_create_shard(const float *d_data, const uint64_t *d_col_ind, const uint64_t *d_row_ind,
+                                            uint64_t n_rows, uint64_t first_col, uint64_t n_cols, const int32_t *d_y,
+                                            void *stream, kmers_model **out) {
     if (!out) return KMERS_ERR_BAD_ARG;
     *out = nullptr;
     if (!d_row_ind || !d_y || n_rows == 0 || n_rows > (1ull << 32) || n_cols == 0 || n_cols >= 0xFFFFFFFFull)
@@ -503,7 +503,7 @@ extern "C" int kmers_hip_model_create(const float *d_data, const uint64_t *d_col
     MD_CHECK(keys_in.alloc(nz * 4));
     MD_CHECK(keys_out.alloc(nz * 4));
     hipLaunchKernelGGL(k_gather_rows, dim3(div_up(m->nnz, 256)), dim3(256), 0, s, (const u32 *)m->xptr, (const u32 *)m->rows,
-                       m->n_m, m->nnz, d_row_ind, d_col_ind, d_data, m->slab_shift, m->n_cols, m->xcol, m->xval, keys_in.as<u32>(),
+                       m->n_m, m->nnz, d_row_ind, d_col_ind, d_data, (u64)first_col, m->slab_shift, m->n_cols, m->xcol, m->xval, keys_in.as<u32>(),
                        pay_in.as<u64>());
     MD_CHECK(hipGetLastError());
     unsigned bits = 1;
@@ -538,7 +538,7 @@ struct Marks {
     int n = 0;
     hipEvent_t ev[12];
     const char *label[12];
-    explicit Marks(hipStream_t s_) : s(s_), on(kk::profile_on()) { mark(nullptr); }
+    explicit Marks(hipStream_t s_, bool enable = true) : s(s_), on(enable && kk::profile_on()) { mark(nullptr); }
     void mark(const char *name) {
         if (!on || n == 12) return;
         if (hipEventCreate(&ev[n]) != hipSuccess) {
@@ -573,20 +573,28 @@ static int spmv(const kmers_model *m, const u32 *ptr, const u32 *idx, const floa
     return KMERS_OK;
 }
 
-extern "C" int kmers_hip_model_logp_grad(kmers_model *m, const float *d_theta, int nograd, double *val_out, float *d_grad,
-                                         void *stream) {
-    if (!m || !d_theta || !val_out || (!nograd && !d_grad)) return KMERS_ERR_BAD_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    Marks marks(s);
-    int rc = spmv<0>(m, m->xptr, m->xcol, m->xval, d_theta, m->xtiles, m->n_m, m->xtheta, s, marks, "k_spmv<x.theta>");
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_logp_terms, dim3(TERM_BLOCKS), dim3(256), 0, s, (const float *)m->xtheta, (const double *)m->ynnz,
-                       m->n_m, m->w, m->partials);
+extern "C" int kmers_hip_model_create(const float *d_data, const uint64_t *d_col_ind, const uint64_t *d_row_ind,
+                                      uint64_t n_rows, uint64_t n_cols, const int32_t *d_y, void *stream,
+                                      kmers_model **out) {
+    return kmers_hip_model_create_shard(d_data, d_col_ind, d_row_ind, n_rows, 0, n_cols, d_y, stream, out);
+}
+
+// phase 1: xtheta = xnnz . theta (asynchronous)
+static int phase_xtheta(kmers_model *m, const float *d_theta, float *d_xtheta, hipStream_t s, Marks &marks) {
+    return spmv<0>(m, m->xptr, m->xcol, m->xval, d_theta, m->xtiles, m->n_m, d_xtheta, s, marks, "k_spmv<x.theta>");
+}
+
+// phase 2: val, w and the gradient from a given xtheta; synchronises
+static int phase_grad(kmers_model *m, const float *d_xtheta, int nograd, double *val_out, float *d_grad, hipStream_t s,
+                      Marks &marks) {
+    hipLaunchKernelGGL(k_logp_terms, dim3(TERM_BLOCKS), dim3(256), 0, s, d_xtheta, (const double *)m->ynnz, m->n_m, m->w,
+                       m->partials);
     marks.mark("k_logp_terms");
     MD_CHECK(hipGetLastError());
     MD_CHECK(hipMemcpyAsync(m->h_partials, m->partials, TERM_BLOCKS * 8, hipMemcpyDeviceToHost, s));
     if (!nograd) {
         marks.mark(nullptr);  // the copy is not a kernel
+        int rc;
         if (m->n_slabs == 1) {
             rc = spmv<1>(m, m->cptr, m->trow, m->tval, m->w, m->ttiles, m->n_cols, d_grad, s, marks, "k_spmv<w.x>");
             if (rc) return rc;
@@ -604,4 +612,27 @@ extern "C" int kmers_hip_model_logp_grad(kmers_model *m, const float *d_theta, i
     for (int i = 0; i < TERM_BLOCKS; ++i) v += m->h_partials[i];
     *val_out = v;
     return KMERS_OK;
+}
+
+extern "C" int kmers_hip_model_logp_grad(kmers_model *m, const float *d_theta, int nograd, double *val_out, float *d_grad,
+                                         void *stream) {
+    if (!m || !d_theta || !val_out || (!nograd && !d_grad)) return KMERS_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    Marks marks(s);
+    const int rc = phase_xtheta(m, d_theta, m->xtheta, s, marks);
+    if (rc) return rc;
+    return phase_grad(m, m->xtheta, nograd, val_out, d_grad, s, marks);
+}
+
+extern "C" int kmers_hip_model_xtheta_into(kmers_model *m, const float *d_theta, float *d_xtheta, void *stream) {
+    if (!m || !d_theta || !d_xtheta) return KMERS_ERR_BAD_ARG;
+    Marks marks((hipStream_t)stream, false);  // asynchronous: nothing to read the events after
+    return phase_xtheta(m, d_theta, d_xtheta, (hipStream_t)stream, marks);
+}
+
+extern "C" int kmers_hip_model_grad_from(kmers_model *m, const float *d_xtheta, int nograd, double *val_out, float *d_grad,
+                                         void *stream) {
+    if (!m || !d_xtheta || !val_out || (!nograd && !d_grad)) return KMERS_ERR_BAD_ARG;
+    Marks marks((hipStream_t)stream);
+    return phase_grad(m, d_xtheta, nograd, val_out, d_grad, (hipStream_t)stream, marks);
 }

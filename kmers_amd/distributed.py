@@ -82,3 +82,69 @@ def build_x_sharded(files, K, L=0, concatenate_subseq=False, device=None, build_
         return None
     d, r, c = merge_csr_parts(gathered, 4 ** K)
     return d, r, c, st.n_rec_total
+
+
+class ShardedModel:
+    """logp_grad with X sharded by columns over the ranks (BASELINE.json configs[4]): every
+    rank builds the CSR of its own isoform range and keeps it in HBM (no host-side merge), counts its share of the
+    reads, and the histogram is all-reduced so that every rank masks the same rows.  One evaluation is then
+
+        xtheta_g = xnnz_g . theta_g            per rank (its columns of theta)
+        xtheta   = all_reduce(sum, xtheta_g)   float32[n_masked]: the path's one exchange step per evaluation
+        val, grad_g = terms(xtheta), (ynnz / xtheta) . xnnz_g          per rank, no further exchange for grad_g
+
+    (reference kmerexpr/utils.py:76-108 on kmerexpr/multinomial_simplex_model.py:56-62's xnnz / ynnz).  The float32
+    partial products are summed by the collective, so the result depends on the number of ranks in the last bits.
+    make_model(store, K, y) -> an object with n_cols, n_masked, xtheta_into(theta, out), grad_from(xtheta, nograd)
+    replaces the HIP model in CPU tests only."""
+
+    def __init__(self, iso_files, reads_files, K, L=0, fastq=False, device=None, count_fn=None, make_model=None):
+        import torch
+        dist = _dist()
+        rank, world = dist.get_rank(), dist.get_world_size()
+        self.K = K
+        xs = Store(iso_files, MODE_X, L=L, shard=rank, n_shards=world)
+        ys = Store(reads_files, MODE_Y_FASTQ if fastq else MODE_Y_FASTA, shard=rank, n_shards=world)
+        self.T, self.first_col, self.n_local = xs.n_rec_total, xs.first_rec, xs.n_rec
+        if make_model is None:
+            dev = torch.device(device or "cuda")
+            counts = ys.to_device(dev).count_y(K)
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+            dx = xs.to_device(dev)
+            buf = dx.x_buffers(K, xs.n_windows(K))
+            dx.build_x(buf)
+            buf["workspace"] = None
+            from .model import DeviceModel
+            self.model = DeviceModel(buf["data"], buf["col_ind"], buf["row_ind"], max(self.n_local, 1), counts,
+                                     first_col=self.first_col)
+            self._x = buf                      # the model holds its own copy of xnnz; X itself stays for the caller
+            self.device = dev
+        else:
+            counts = count_fn(ys, K)
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+            self.model = make_model(xs, K, counts)
+            self.device = torch.device("cpu")
+        self.N = int(counts.sum(dtype=torch.int64).item())
+        self._xtheta = torch.empty(self.model.n_masked, dtype=torch.float32, device=self.device)
+        self._theta = torch.zeros(max(self.n_local, 1), dtype=torch.float32, device=self.device)
+        self._full = torch.zeros(self.T, dtype=torch.float32, device=self.device)
+
+    def logp_grad(self, theta, nograd=False):
+        """theta: numpy [T] (the same on every rank).  Returns val, or (val, grad numpy float32 [T]), on every rank:
+        the data terms only, like kmers_hip_model_logp_grad."""
+        import torch
+        dist = _dist()
+        theta = np.asarray(theta).astype(np.float32)
+        assert theta.shape == (self.T,)
+        lo, n = self.first_col, self.n_local
+        self._theta[:n].copy_(torch.from_numpy(theta[lo:lo + n]))
+        self.model.xtheta_into(self._theta, self._xtheta)
+        dist.all_reduce(self._xtheta, op=dist.ReduceOp.SUM)
+        out = self.model.grad_from(self._xtheta, nograd=nograd)
+        if nograd:
+            return out
+        val, grad_local = out
+        self._full.zero_()
+        self._full[lo:lo + n].copy_(grad_local[:n])
+        dist.all_reduce(self._full, op=dist.ReduceOp.SUM)     # T floats: assembling the shards, not a reduction of data
+        return val, self._full.cpu().numpy()

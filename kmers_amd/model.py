@@ -12,9 +12,11 @@ from .store import _stream_ptr
 class DeviceModel:
     """xnnz = x[y != 0] (and its column-sorted copy), ynnz = y[y != 0] / sum(y), in HBM."""
 
-    def __init__(self, data, col_ind, row_ind, n_cols, y, stream=None):
+    def __init__(self, data, col_ind, row_ind, n_cols, y, stream=None, first_col=0):
         """data f32[>=nnz], col_ind i64/u64[>=nnz], row_ind i64/u64[n_rows + 1], y int32[n_rows]: torch tensors on the
-        GPU, e.g. the buffers DeviceStore.build_x filled and the counts of DeviceStore.count_y."""
+        GPU, e.g. the buffers DeviceStore.build_x filled and the counts of DeviceStore.count_y.  For a column shard
+        (multi-GPU fit) n_cols is the shard's width, first_col its first global column and y the histogram of all
+        reads."""
         import torch
         self._lib = _lib.handle()
         assert data.dtype == torch.float32 and col_ind.dtype == torch.int64 and row_ind.dtype == torch.int64
@@ -23,9 +25,10 @@ class DeviceModel:
         self.device = y.device
         self.n_rows, self.n_cols = y.numel(), int(n_cols)
         h = C.c_void_p()
-        rc = self._lib.kmers_hip_model_create(data.data_ptr(), col_ind.data_ptr(), row_ind.data_ptr(), self.n_rows,
-                                              self.n_cols, y.data_ptr(), _stream_ptr(stream), C.byref(h))
-        _lib.check(rc, "kmers_hip_model_create")
+        rc = self._lib.kmers_hip_model_create_shard(data.data_ptr(), col_ind.data_ptr(), row_ind.data_ptr(), self.n_rows,
+                                                    int(first_col), self.n_cols, y.data_ptr(), _stream_ptr(stream),
+                                                    C.byref(h))
+        _lib.check(rc, "kmers_hip_model_create_shard")
         self._h = h
         self.n_masked = int(self._lib.kmers_hip_model_n_masked(h))
         self.nnz = int(self._lib.kmers_hip_model_nnz(h))
@@ -62,6 +65,23 @@ class DeviceModel:
         rc = self._lib.kmers_hip_model_logp_grad(self._h, theta.data_ptr(), 1 if nograd else 0, C.byref(val),
                                                  None if nograd else self._grad.data_ptr(), _stream_ptr(stream))
         _lib.check(rc, "kmers_hip_model_logp_grad")
+        return val.value if nograd else (val.value, self._grad)
+
+    def xtheta_into(self, theta, out, stream=None):
+        """out (float32 device tensor [n_masked]) = xnnz . theta of this (column shard of the) model; asynchronous."""
+        import torch
+        assert theta.dtype == torch.float32 and theta.numel() == self.n_cols and theta.is_cuda and theta.is_contiguous()
+        assert out.dtype == torch.float32 and out.numel() == self.n_masked and out.is_cuda and out.is_contiguous()
+        rc = self._lib.kmers_hip_model_xtheta_into(self._h, theta.data_ptr(), out.data_ptr(), _stream_ptr(stream))
+        _lib.check(rc, "kmers_hip_model_xtheta_into")
+        return out
+
+    def grad_from(self, xtheta, nograd=False, stream=None):
+        """val (and this model's gradient entries) from a given xtheta, e.g. the sum over column shards."""
+        val = C.c_double(0.0)
+        rc = self._lib.kmers_hip_model_grad_from(self._h, xtheta.data_ptr(), 1 if nograd else 0, C.byref(val),
+                                                 None if nograd else self._grad.data_ptr(), _stream_ptr(stream))
+        _lib.check(rc, "kmers_hip_model_grad_from")
         return val.value if nograd else (val.value, self._grad)
 
     def _read(self, what, dtype):

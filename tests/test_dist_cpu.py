@@ -65,3 +65,48 @@ def test_csr_merge_unit():
     r, c = np.nonzero(whole)
     assert np.array_equal(col, c.astype(np.uint64)) and np.array_equal(data, whole[r, c].astype(np.float32))
     assert np.array_equal(np.diff(row.astype(np.int64)), np.bincount(r, minlength=n_rows))
+
+
+def _run_model_workers(mode, world, iso, reads, K, out, timeout=300):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), KMER_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_model_worker.py"), mode, iso, reads, str(K),
+                                       out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o, _ = p.communicate(timeout=timeout)
+        assert p.returncode == 0, o.decode()[-2000:]
+    return [np.load(out + f".rank{r}.npz") for r in range(world)]
+
+
+def check_sharded_model(oracle, res, iso, reads, K):
+    """Every rank's (val, grad) against the single-process float64 oracle on the whole X and y."""
+    from scipy.sparse import csr_matrix
+    from oracle import logp_grad as orc
+    rc, data, row, col, n_cols = oracle.x([iso], K)
+    rc2, y = oracle.y([reads], K)
+    assert rc == 0 and rc2 == 0
+    x = csr_matrix((data, col.astype(np.int64), row.astype(np.int64)), shape=(4 ** K, n_cols))
+    rows, xnnz, ynnz = orc.model_setup(x, y)
+    theta = res[0]["theta"]
+    want_val, want_grad, _ = orc.logp_grad_ref(theta, 1.0, xnnz, ynnz, np.ones(n_cols))
+    covered = 0
+    for r in res:
+        assert int(r["N"]) == int(y.sum()) and int(r["first"]) == covered
+        covered += int(r["n"])
+        # xtheta is a sum of float32 partial products here (one rounding per rank), hence the wider tolerance
+        np.testing.assert_allclose(float(r["val"]), want_val, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(r["grad"], want_grad, rtol=5e-6, atol=1e-30)
+        assert np.array_equal(r["grad"], res[0]["grad"]) and float(r["val"]) == float(res[0]["val"])
+    assert covered == n_cols
+
+
+@pytest.mark.parametrize("world,K", [(2, 6), (3, 9)])
+def test_sharded_logp_grad(oracle, tmp_path, world, K):
+    """ShardedModel: X sharded by columns, y all-reduced, one all-reduce of xtheta per evaluation."""
+    iso = os.path.join(kmtest.INP, "syn_small.fsa")
+    reads = os.path.join(kmtest.INP, "syn_small.fsa")            # the transcriptome's own k-mers: every row of y has an X row
+    res = _run_model_workers("cpu", world, iso, reads, K, str(tmp_path / "m"))
+    check_sharded_model(oracle, res, iso, reads, K)

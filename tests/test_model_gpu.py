@@ -211,3 +211,14 @@ def test_all_zero_y_is_rejected(syn):
     x, y = xy(syn, 4)
     with pytest.raises(RuntimeError, match="bad argument"):
         multinomial_simplex_model(x, np.zeros_like(y))
+
+
+def test_sharded_model_rehearsal_two_ranks_one_gpu(oracle, tmp_path):
+    """kmers_amd.distributed.ShardedModel with the real HIP model on two ranks that share this box's GPU (gloo for the
+    collective): the multi-GPU control flow of BASELINE.json configs[4]."""
+    import os
+    from tests import kmtest
+    from tests.test_dist_cpu import _run_model_workers, check_sharded_model
+    iso = os.path.join(kmtest.INP, "syn_small.fsa")
+    res = _run_model_workers("gpu", 2, iso, iso, 10, str(tmp_path / "m"))
+    check_sharded_model(oracle, res, iso, iso, 10)
