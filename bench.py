@@ -191,7 +191,7 @@ def bench_model(args, K, dev, rank, world, fence):
     kernel_bytes = {      # per launch: 8 bytes per non-zero, row pointers in, one float per row out, the gathered vector once
         "k_spmv<x.theta>": 8 * nnz + 4 * (n_m + 1) + 4 * n_m + 4 * T,
         "k_spmv<w.x>": 8 * nnz + 4 * (T + 1) + 4 * T + 4 * n_m,
-        "k_logp_terms": (4 + 8 + 4) * n_m,
+        "k_logp_terms": (4 + 4 + 4) * n_m,
     }
     dom = max((r for r in table if r[0] in kernel_bytes), key=lambda r: r[1])
     avg_ms = dom[1] / dom[2]

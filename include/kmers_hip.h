@@ -156,7 +156,7 @@ typedef struct kmers_model kmers_model;
 
 /* Build the model from X as kmers_hip_build_x left it in HBM (d_data f32[nnz], d_col_ind u64[nnz],
  * d_row_ind u64[n_rows + 1]) and the histogram d_y int32[n_rows] of kmers_hip_count_y.  Allocates (library-owned
- * device memory, about 16 bytes per non-zero of xnnz plus 24 per masked row; twice that while it is being built)
+ * device memory, about 16 bytes per non-zero of xnnz plus 20 per masked row; twice that while it is being built)
  * and synchronises `stream`.  Limits: n_cols, masked rows and non-zeros of xnnz below 2^32 (KMERS_ERR_TOO_LARGE);
  * y must have a non-zero (KMERS_ERR_BAD_ARG). */
 int kmers_hip_model_create(const float *d_data, const uint64_t *d_col_ind, const uint64_t *d_row_ind, uint64_t n_rows,
@@ -191,7 +191,7 @@ int kmers_hip_model_logp_grad(kmers_model *m, const float *d_theta, int nograd, 
 
 /* logp_grad in two steps, for column shards: d_xtheta f32[n_masked] (caller's buffer) = this shard's xnnz.theta
  * (asynchronous); the caller sums the shards' buffers (one all-reduce over RCCL: the path's only exchange step);
- * then val, and this shard's gradient entries, from the summed xtheta (synchronises `stream`).
+ * then val, and this shard's gradient entries, from the summed xtheta (16-byte aligned; synchronises `stream`).
  * kmers_hip_model_logp_grad is the two steps on the model's own buffer. */
 int kmers_hip_model_xtheta_into(kmers_model *m, const float *d_theta, float *d_xtheta, void *stream);
 int kmers_hip_model_grad_from(kmers_model *m, const float *d_xtheta, int nograd, double *val_out, float *d_grad,

@@ -44,7 +44,11 @@ constexpr int SP_IPT = SP_IPT_;         // consecutive non-zeros per thread (a m
 constexpr u32 SP_TILE = SP_NT * SP_IPT; // non-zeros per workgroup
 constexpr u32 SP_PTR_LDS = 4096;        // row pointers of one tile staged in LDS when they fit
 constexpr u32 NO_ROW = 0xFFFFFFFFu;
-constexpr int TERM_BLOCKS = 1024;       // k_logp_terms: partial sums, added on the host in index order
+#ifndef SP_XCDS_
+#define SP_XCDS_ 8
+#endif
+constexpr u32 SP_XCDS = SP_XCDS_;       // XCDs of an MI355X (1 = plain blockIdx order, for A/B runs)
+constexpr int TERM_BLOCKS = 2048;       // k_logp_terms: partial sums, added on the host in index order
 
 #define MD_CHECK(expr)                                                                                              \
     do {                                                                                                            \
@@ -89,12 +93,18 @@ __global__ __launch_bounds__(256) void k_tile_rows(const u32 *__restrict__ ptr, 
 template <int WHICH, class OutT>
 __global__ __launch_bounds__(SP_NT) void k_spmv(const u32 *__restrict__ ptr, const u32 *__restrict__ idx,
                                                 const float *__restrict__ val, const float *__restrict__ vec,
-                                                const uint2 *__restrict__ tile_rows, u32 n, u32 nnz,
+                                                const uint2 *__restrict__ tile_rows, u32 n, u32 nnz, u32 n_tiles,
                                                 OutT *__restrict__ out, TileCarry *__restrict__ carry) {
     __shared__ u32 s_ptr[SP_PTR_LDS];
     __shared__ double s_wave_a[SP_NT / 64];
     __shared__ u32 s_wave_f[SP_NT / 64];
-    const u32 t = threadIdx.x, tile = blockIdx.x;
+    // Workgroups go to the 8 XCDs round-robin; give every XCD one contiguous eighth of the tiles, so that the part of
+    // the gathered vector a run of tiles shares (a row slab of w: 2 MB) is fetched into one L2 instead of eight.
+    const u32 t = threadIdx.x;
+    // (The forward product gathers theta, which every L2 holds whole: plain order is 2 % faster there.)
+    const u32 per_xcd = (n_tiles + SP_XCDS - 1) / SP_XCDS;
+    const u32 tile = WHICH == 1 ? (blockIdx.x % SP_XCDS) * per_xcd + blockIdx.x / SP_XCDS : blockIdx.x;
+    if (tile >= n_tiles) return;
     const u32 base = tile * SP_TILE;
     const u32 tile_end = min(base + SP_TILE, nnz);
     const u32 k0 = base + t * SP_IPT;
@@ -238,13 +248,28 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const double *__restrict__
     grad[c] = (float)s;
 }
 
-// val partials and w = ynnz / xtheta (float64 / float32 -> float32, as utils.py:102 stores it)
-__global__ __launch_bounds__(256) void k_logp_terms(const float *__restrict__ xtheta, const double *__restrict__ ynnz, u32 n,
-                                                    float *__restrict__ w, double *__restrict__ partials) {
+// val partials and w = ynnz / xtheta (float64 / float32 -> float32, as utils.py:102 stores it).  ynnz[i] is formed
+// here as ycnt[i] / sum(y) in float64 -- the value multinomial_simplex_model.py:62 stores -- from the 4-byte count.
+__global__ __launch_bounds__(256) void k_logp_terms(const float *__restrict__ xtheta, const int32_t *__restrict__ ycnt,
+                                                    double sum_y, u32 n, float *__restrict__ w,
+                                                    double *__restrict__ partials) {
     __shared__ double s_part[4];
     double s = 0.0;
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
-        const double x = (double)xtheta[i], y = ynnz[i];
+    const u32 n4 = n / 4;  // 16-byte loads and stores: the three arrays are hipMalloc'ed
+    for (u64 q = (u64)blockIdx.x * 256 + threadIdx.x; q < n4; q += (u64)gridDim.x * 256) {
+        const float4 x4 = reinterpret_cast<const float4 *>(xtheta)[q];
+        const int4 c4 = reinterpret_cast<const int4 *>(ycnt)[q];
+        const double x0 = x4.x, x1 = x4.y, x2 = x4.z, x3 = x4.w;
+        const double y0 = c4.x / sum_y, y1 = c4.y / sum_y, y2 = c4.z / sum_y, y3 = c4.w / sum_y;
+        s += y0 * log(x0);
+        s += y1 * log(x1);
+        s += y2 * log(x2);
+        s += y3 * log(x3);
+        reinterpret_cast<float4 *>(w)[q] = make_float4((float)(y0 / x0), (float)(y1 / x1), (float)(y2 / x2), (float)(y3 / x3));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - 4 * n4) {
+        const u32 i = 4 * n4 + threadIdx.x;
+        const double x = (double)xtheta[i], y = (double)ycnt[i] / sum_y;
         s += y * log(x);
         w[i] = (float)(y / x);
     }
@@ -273,11 +298,10 @@ __global__ __launch_bounds__(256) void k_y_sum(const int32_t *__restrict__ y, u6
     if (threadIdx.x == 0) atomicAdd(stats, (unsigned long long)(s_part[0] + s_part[1] + s_part[2] + s_part[3]));
 }
 
-// lens[i] = length of X's row rows[i]; ynnz[i] = y[rows[i]] / sum(y); stats[1] += sum of lens
+// lens[i] = length of X's row rows[i]; ycnt[i] = y[rows[i]]; stats[1] += sum of lens
 __global__ __launch_bounds__(256) void k_row_lens(const u32 *__restrict__ rows, u32 n_m, const u64 *__restrict__ row_ind,
-                                                  const int32_t *__restrict__ y, const unsigned long long *stats_in,
-                                                  u32 *__restrict__ lens, double *__restrict__ ynnz,
-                                                  unsigned long long *stats) {
+                                                  const int32_t *__restrict__ y, u32 *__restrict__ lens,
+                                                  int32_t *__restrict__ ycnt, unsigned long long *stats) {
     __shared__ unsigned long long s_part[4];
     const u32 i = blockIdx.x * 256 + threadIdx.x;
     unsigned long long len = 0;
@@ -285,7 +309,7 @@ __global__ __launch_bounds__(256) void k_row_lens(const u32 *__restrict__ rows, 
         const u64 r = rows[i];
         len = row_ind[r + 1] - row_ind[r];
         lens[i] = (u32)len;  // the host rejects the model when the total does not fit 32 bits
-        ynnz[i] = (double)y[r] / (double)(long long)stats_in[0];
+        ycnt[i] = y[r];
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) len += __shfl_down(len, d);
@@ -364,7 +388,8 @@ struct kmers_model {
     long long sum_y = 0;
     u32 *rows = nullptr, *xptr = nullptr, *xcol = nullptr, *cptr = nullptr, *trow = nullptr;
     float *xval = nullptr, *tval = nullptr, *xtheta = nullptr, *w = nullptr;
-    double *ynnz = nullptr, *partials = nullptr, *h_partials = nullptr;
+    int32_t *ycnt = nullptr;  // y[ymask]; ynnz = ycnt / sum_y
+    double *partials = nullptr, *h_partials = nullptr;
     TileCarry *carry = nullptr;
     double *gpart = nullptr;  // n_slabs > 1: per-slab partial gradients
     uint2 *xtiles = nullptr, *ttiles = nullptr;  // k_tile_rows of xnnz and of its column-sorted copy
@@ -373,7 +398,7 @@ struct kmers_model {
 extern "C" void kmers_hip_model_free(kmers_model *m) {
     if (!m) return;
     for (void *p : {(void *)m->rows, (void *)m->xptr, (void *)m->xcol, (void *)m->cptr, (void *)m->trow, (void *)m->xval,
-                    (void *)m->tval, (void *)m->xtheta, (void *)m->w, (void *)m->ynnz, (void *)m->partials, (void *)m->carry,
+                    (void *)m->tval, (void *)m->xtheta, (void *)m->w, (void *)m->ycnt, (void *)m->partials, (void *)m->carry,
                     (void *)m->xtiles, (void *)m->ttiles, (void *)m->gpart})
         if (p) (void)hipFree(p);
     if (m->h_partials) (void)hipHostFree(m->h_partials);
@@ -439,10 +464,10 @@ extern "C" int kmers_hip_model_create_shard(const float *d_data, const uint64_t 
 
     // 2. row pointers of xnnz, ynnz
     MD_CHECK(hipMalloc((void **)&m->xptr, ((size_t)m->n_m + 1) * 4));
-    MD_CHECK(hipMalloc((void **)&m->ynnz, (size_t)m->n_m * 8));
+    MD_CHECK(hipMalloc((void **)&m->ycnt, (size_t)m->n_m * 4));
     MD_CHECK(hipMemsetAsync(m->xptr + m->n_m, 0, 4, s));
     hipLaunchKernelGGL(k_row_lens, dim3(div_up(m->n_m, 256)), dim3(256), 0, s, (const u32 *)m->rows, m->n_m, d_row_ind, d_y,
-                       (const unsigned long long *)stats.p, m->xptr, m->ynnz, stats.as<unsigned long long>());
+                       m->xptr, m->ycnt, stats.as<unsigned long long>());
     MD_CHECK(hipGetLastError());
     MD_CHECK(hipMemcpyAsync(h_stats, stats.p, 16, hipMemcpyDeviceToHost, s));
     MD_CHECK(hipStreamSynchronize(s));
@@ -564,7 +589,8 @@ static int spmv(const kmers_model *m, const u32 *ptr, const u32 *idx, const floa
         MD_CHECK(hipMemsetAsync(out, 0, (size_t)n * sizeof(OutT), s));
         return KMERS_OK;
     }
-    hipLaunchKernelGGL((k_spmv<WHICH, OutT>), dim3(m->n_tiles), dim3(SP_NT), 0, s, ptr, idx, val, vec, tiles, n, m->nnz, out, m->carry);
+    hipLaunchKernelGGL((k_spmv<WHICH, OutT>), dim3(div_up(m->n_tiles, SP_XCDS) * SP_XCDS), dim3(SP_NT), 0, s, ptr, idx, val, vec,
+                       tiles, n, m->nnz, m->n_tiles, out, m->carry);
     marks.mark(label);
     hipLaunchKernelGGL(k_spmv_fixup<OutT>, dim3(div_up(m->n_tiles, 256)), dim3(256), 0, s, (const TileCarry *)m->carry, m->n_tiles,
                        out);
@@ -587,8 +613,8 @@ static int phase_xtheta(kmers_model *m, const float *d_theta, float *d_xtheta, h
 // phase 2: val, w and the gradient from a given xtheta; synchronises
 static int phase_grad(kmers_model *m, const float *d_xtheta, int nograd, double *val_out, float *d_grad, hipStream_t s,
                       Marks &marks) {
-    hipLaunchKernelGGL(k_logp_terms, dim3(TERM_BLOCKS), dim3(256), 0, s, d_xtheta, (const double *)m->ynnz, m->n_m, m->w,
-                       m->partials);
+    hipLaunchKernelGGL(k_logp_terms, dim3(TERM_BLOCKS), dim3(256), 0, s, d_xtheta, (const int32_t *)m->ycnt, (double)m->sum_y, m->n_m,
+                       m->w, m->partials);
     marks.mark("k_logp_terms");
     MD_CHECK(hipGetLastError());
     MD_CHECK(hipMemcpyAsync(m->h_partials, m->partials, TERM_BLOCKS * 8, hipMemcpyDeviceToHost, s));
@@ -632,7 +658,7 @@ extern "C" int kmers_hip_model_xtheta_into(kmers_model *m, const float *d_theta,
 
 extern "C" int kmers_hip_model_grad_from(kmers_model *m, const float *d_xtheta, int nograd, double *val_out, float *d_grad,
                                          void *stream) {
-    if (!m || !d_xtheta || !val_out || (!nograd && !d_grad)) return KMERS_ERR_BAD_ARG;
+    if (!m || !d_xtheta || ((uintptr_t)d_xtheta & 15) || !val_out || (!nograd && !d_grad)) return KMERS_ERR_BAD_ARG;
     Marks marks((hipStream_t)stream);
     return phase_grad(m, d_xtheta, nograd, val_out, d_grad, (hipStream_t)stream, marks);
 }
