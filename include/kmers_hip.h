@@ -158,7 +158,8 @@ typedef struct kmers_model kmers_model;
  * d_row_ind u64[n_rows + 1]) and the histogram d_y int32[n_rows] of kmers_hip_count_y.  Allocates (library-owned
  * device memory, about 16 bytes per non-zero of xnnz plus 20 per masked row; twice that while it is being built)
  * and synchronises `stream`.  Limits: n_cols, masked rows and non-zeros of xnnz below 2^32 (KMERS_ERR_TOO_LARGE);
- * y must have a non-zero (KMERS_ERR_BAD_ARG). */
+ * y must have a non-zero and every column index of the masked rows must lie in the model's range
+ * (KMERS_ERR_BAD_ARG). */
 int kmers_hip_model_create(const float *d_data, const uint64_t *d_col_ind, const uint64_t *d_row_ind, uint64_t n_rows,
                            uint64_t n_cols, const int32_t *d_y, void *stream, kmers_model **out);
 void kmers_hip_model_free(kmers_model *m);

@@ -324,14 +324,17 @@ __global__ __launch_bounds__(256) void k_gather_rows(const u32 *__restrict__ xpt
                                                      u32 nnz, const u64 *__restrict__ row_ind, const u64 *__restrict__ col_ind,
                                                      const float *__restrict__ data, u64 first_col, u32 slab_shift, u32 n_cols,
                                                      u32 *__restrict__ xcol, float *__restrict__ xval,
-                                                     u32 *__restrict__ keys, u64 *__restrict__ payload) {
+                                                     u32 *__restrict__ keys, u64 *__restrict__ payload,
+                                                     unsigned long long *stats) {
     const u32 k = blockIdx.x * 256 + threadIdx.x;
     if (k >= nnz) return;
     auto P = [&](u32 r) { return xptr[r]; };
     const u32 i = last_row_le(P, 0u, n_m - 1, k);
     const u64 src = row_ind[rows[i]] + (k - xptr[i]);
     const float v = data[src];
-    const u32 col = (u32)(col_ind[src] - first_col);  // the host checked nothing: a shard's columns are its own range
+    const u64 gcol = col_ind[src] - first_col;
+    if (gcol >= n_cols) stats[2] = 1;  // a column outside [first_col, first_col + n_cols): the host rejects the model
+    const u32 col = gcol < n_cols ? (u32)gcol : 0u;
     xcol[k] = col;
     xval[k] = v;
     keys[k] = (i >> slab_shift) * n_cols + col;
@@ -438,9 +441,9 @@ extern "C" int kmers_hip_model_create_shard(const float *d_data, const uint64_t 
 
     // 1. sum(y), the masked rows
     Dev stats, count, tmp;
-    MD_CHECK(stats.alloc(16));
+    MD_CHECK(stats.alloc(24));
     MD_CHECK(count.alloc(8));
-    MD_CHECK(hipMemsetAsync(stats.p, 0, 16, s));
+    MD_CHECK(hipMemsetAsync(stats.p, 0, 24, s));
     hipLaunchKernelGGL(k_y_sum, dim3(2048), dim3(256), 0, s, d_y, (u64)n_rows, stats.as<unsigned long long>());
     MD_CHECK(hipGetLastError());
     Dev all_rows;  // selection output is sized for the worst case, then trimmed
@@ -452,7 +455,7 @@ extern "C" int kmers_hip_model_create_shard(const float *d_data, const uint64_t 
     MD_CHECK(tmp.alloc(tmp_bytes));
     MD_CHECK(rocprim::select(tmp.p, tmp_bytes, ids, flags, all_rows.as<u32>(), count.as<size_t>(), (size_t)n_rows, s));
     size_t n_sel = 0;
-    unsigned long long h_stats[2] = {0, 0};
+    unsigned long long h_stats[3] = {0, 0, 0};
     MD_CHECK(hipMemcpyAsync(&n_sel, count.p, sizeof n_sel, hipMemcpyDeviceToHost, s));
     MD_CHECK(hipMemcpyAsync(h_stats, stats.p, 8, hipMemcpyDeviceToHost, s));
     MD_CHECK(hipStreamSynchronize(s));
@@ -529,7 +532,7 @@ extern "C" int kmers_hip_model_create_shard(const float *d_data, const uint64_t 
     MD_CHECK(keys_out.alloc(nz * 4));
     hipLaunchKernelGGL(k_gather_rows, dim3(div_up(m->nnz, 256)), dim3(256), 0, s, (const u32 *)m->xptr, (const u32 *)m->rows,
                        m->n_m, m->nnz, d_row_ind, d_col_ind, d_data, (u64)first_col, m->slab_shift, m->n_cols, m->xcol, m->xval, keys_in.as<u32>(),
-                       pay_in.as<u64>());
+                       pay_in.as<u64>(), stats.as<unsigned long long>());
     MD_CHECK(hipGetLastError());
     unsigned bits = 1;
     while (bits < 32 && (1ull << bits) < m->n_trows) ++bits;
@@ -550,7 +553,9 @@ extern "C" int kmers_hip_model_create_shard(const float *d_data, const uint64_t 
     hipLaunchKernelGGL(k_tile_rows, dim3(div_up(m->n_tiles, 256)), dim3(256), 0, s, (const u32 *)m->cptr, m->n_trows, m->nnz,
                        m->n_tiles, m->ttiles);
     MD_CHECK(hipGetLastError());
+    MD_CHECK(hipMemcpyAsync(h_stats, stats.p, 24, hipMemcpyDeviceToHost, s));
     MD_CHECK(hipStreamSynchronize(s));
+    if (h_stats[2]) return KMERS_ERR_BAD_ARG;  // a column outside this model's range: the products would gather past theta
     guard.m = nullptr;
     *out = m;
     return KMERS_OK;

@@ -213,6 +213,21 @@ def test_all_zero_y_is_rejected(syn):
         multinomial_simplex_model(x, np.zeros_like(y))
 
 
+def test_columns_outside_the_model_are_rejected(syn):
+    """A column index beyond n_cols (or a wrong first_col for a shard) would make the products gather past theta:
+    the model is refused instead."""
+    import torch
+    from kmers_amd.model import DeviceModel
+    x, y = xy(syn, 5)
+    up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()
+    args = (up(x.data, np.float32), up(x.indices, np.int64), up(x.indptr, np.int64))
+    DeviceModel(*args, x.shape[1], up(y, np.int32))
+    with pytest.raises(RuntimeError, match="bad argument"):
+        DeviceModel(*args, x.shape[1] - 1, up(y, np.int32))
+    with pytest.raises(RuntimeError, match="bad argument"):
+        DeviceModel(*args, x.shape[1], up(y, np.int32), first_col=1)
+
+
 def test_sharded_model_rehearsal_two_ranks_one_gpu(oracle, tmp_path):
     """kmers_amd.distributed.ShardedModel with the real HIP model on two ranks that share this box's GPU (gloo for the
     collective): the multi-GPU control flow of BASELINE.json configs[4]."""
