@@ -47,3 +47,15 @@ def test_gradient_matches_finite_differences(oracle):
             fd = (orc.logp_grad_ref(theta + e, beta, xnnz, ynnz, lengths, nograd=True) -
                   orc.logp_grad_ref(theta - e, beta, xnnz, ynnz, lengths, nograd=True)) / (2 * e[j])
             assert abs(fd - grad[j]) < 2e-3 * max(1.0, abs(grad[j]))
+
+
+def test_model_has_no_cpu_fallback(oracle):
+    """Without a GPU the model refuses to be built (no silent scipy path behind the reference's class name)."""
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from kmers_amd.multinomial_simplex_model import multinomial_simplex_model
+    x = x_from_oracle(oracle, os.path.join(kmtest.INP, "ref_test1.fsa"), 1)
+    with pytest.raises((RuntimeError, AssertionError)):
+        multinomial_simplex_model(x, np.array([3, 0, 1, 4], np.int32))
