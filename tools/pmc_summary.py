@@ -11,7 +11,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            name = r["Kernel_Name"].split("(")[0]
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(acc):
     if "kk::" not in k and "k_spmv" not in k and "k_logp_terms" not in k:
