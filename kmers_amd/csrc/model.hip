@@ -36,13 +36,20 @@ namespace {
 using u32 = uint32_t;
 using u64 = uint64_t;
 
-constexpr int SP_NT = 256;              // threads per workgroup of k_spmv
+// Threads per workgroup of k_spmv, chosen per product when the model is built: 1024 when the rows are long (>= 512
+// non-zeros on average: K <= 9), else 256.  Same-run A/B: K=8 2.18 -> 2.04 ms per logp_grad with 1024, K=12 / K=14
+// 2.95 -> 3.01 / 2.61 -> 2.94 ms (short rows: the walks diverge and a bigger workgroup waits longer at its barriers).
+constexpr int SP_NT_SHORT = 256, SP_NT_LONG = 1024;
+constexpr u32 SP_LONG_ROWS = 512;
 #ifndef SP_IPT_
 #define SP_IPT_ 8
 #endif
 constexpr int SP_IPT = SP_IPT_;         // consecutive non-zeros per thread (a multiple of 4: 16-byte loads)
-constexpr u32 SP_TILE = SP_NT * SP_IPT; // non-zeros per workgroup
-constexpr u32 SP_PTR_LDS = 4096;        // row pointers of one tile staged in LDS when they fit
+constexpr u32 SP_TILE_MAX = SP_NT_LONG * SP_IPT;  // non-zeros per workgroup: threads x SP_IPT
+#ifndef SP_PTR_LDS_
+#define SP_PTR_LDS_ 4096
+#endif
+constexpr u32 SP_PTR_LDS = SP_PTR_LDS_;  // row pointers of one tile staged in LDS when they fit
 constexpr u32 NO_ROW = 0xFFFFFFFFu;
 #ifndef SP_XCDS_
 #define SP_XCDS_ 8
@@ -78,24 +85,25 @@ __device__ __forceinline__ u32 last_row_le(const P &ptr, u32 lo, u32 hi, u32 k) 
 }
 
 // first / last row with a non-zero in every tile, found once per model (the row structure never changes)
-__global__ __launch_bounds__(256) void k_tile_rows(const u32 *__restrict__ ptr, u32 n, u32 nnz, u32 n_tiles,
+__global__ __launch_bounds__(256) void k_tile_rows(const u32 *__restrict__ ptr, u32 n, u32 nnz, u32 n_tiles, u32 tile_nnz,
                                                    uint2 *__restrict__ tile_rows) {
     const u32 tile = blockIdx.x * 256 + threadIdx.x;
     if (tile >= n_tiles) return;
     auto gptr = [&](u32 r) { return ptr[r]; };
-    const u32 base = tile * SP_TILE, tile_end = min(base + SP_TILE, nnz);
+    const u32 base = tile * tile_nnz, tile_end = min(base + tile_nnz, nnz);
     const u32 lo = tile == 0 ? 0u : last_row_le(gptr, 0u, n - 1, base);  // tile 0 also owns the empty rows in front
     tile_rows[tile] = make_uint2(lo, last_row_le(gptr, lo, n - 1, tile_end - 1));
 }
 
 // out[r] = sum_{k in [ptr[r], ptr[r+1])} val[k] * vec[idx[k]]     for r < n;  ptr[n] == nnz > 0
 // WHICH only names the instantiation in profiles: 0 = xnnz . theta, 1 = w . xnnz (on the column-sorted copy)
-template <int WHICH, class OutT>
+template <int WHICH, class OutT, int SP_NT>
 __global__ __launch_bounds__(SP_NT) void k_spmv(const u32 *__restrict__ ptr, const u32 *__restrict__ idx,
                                                 const float *__restrict__ val, const float *__restrict__ vec,
                                                 const uint2 *__restrict__ tile_rows, u32 n, u32 nnz, u32 n_tiles,
                                                 OutT *__restrict__ out, TileCarry *__restrict__ carry) {
     __shared__ u32 s_ptr[SP_PTR_LDS];
+    constexpr u32 SP_TILE = SP_NT * SP_IPT;
     __shared__ double s_wave_a[SP_NT / 64];
     __shared__ u32 s_wave_f[SP_NT / 64];
     // Workgroups go to the 8 XCDs round-robin; give every XCD one contiguous eighth of the tiles, so that the part of
@@ -386,7 +394,8 @@ static inline u32 div_up(u64 a, u32 b) { return (u32)((a + b - 1) / b); }
 struct kmers_model {
     int device = 0;
     u64 n_rows = 0;
-    u32 n_cols = 0, n_m = 0, nnz = 0, n_tiles = 0;
+    u32 n_cols = 0, n_m = 0, nnz = 0;
+    u32 x_nt = SP_NT_SHORT, t_nt = SP_NT_SHORT, x_tiles = 0, t_tiles = 0;  // workgroup size and tile count per product
     u32 slab_shift = 31, n_slabs = 1, n_trows = 0;  // transposed copy: n_slabs row slabs x n_cols columns = n_trows rows
     long long sum_y = 0;
     u32 *rows = nullptr, *xptr = nullptr, *xcol = nullptr, *cptr = nullptr, *trow = nullptr;
@@ -475,9 +484,10 @@ extern "C" int kmers_hip_model_create_shard(const float *d_data, const uint64_t 
     MD_CHECK(hipMemcpyAsync(h_stats, stats.p, 16, hipMemcpyDeviceToHost, s));
     MD_CHECK(hipStreamSynchronize(s));
     all_rows.reset();
-    if (h_stats[1] >= 0xFFFFFFFFull - SP_TILE) return KMERS_ERR_TOO_LARGE;
+    if (h_stats[1] >= 0xFFFFFFFFull - SP_TILE_MAX) return KMERS_ERR_TOO_LARGE;
     m->nnz = (u32)h_stats[1];
-    m->n_tiles = div_up(m->nnz, SP_TILE);
+    m->x_nt = (m->nnz / m->n_m >= SP_LONG_ROWS) ? SP_NT_LONG : SP_NT_SHORT;
+    m->x_tiles = div_up(m->nnz, m->x_nt * SP_IPT);
     {
         size_t b = 0;
         Dev t2;
@@ -492,7 +502,7 @@ extern "C" int kmers_hip_model_create_shard(const float *d_data, const uint64_t 
     MD_CHECK(hipMalloc((void **)&m->w, (size_t)m->n_m * 4));
     MD_CHECK(hipMalloc((void **)&m->partials, TERM_BLOCKS * 8));
     MD_CHECK(hipHostMalloc((void **)&m->h_partials, TERM_BLOCKS * 8, hipHostMallocDefault));
-    MD_CHECK(hipMalloc((void **)&m->carry, ((size_t)m->n_tiles + 1) * sizeof(TileCarry)));
+    MD_CHECK(hipMalloc((void **)&m->carry, ((size_t)div_up(m->nnz, SP_NT_SHORT * SP_IPT) + 1) * sizeof(TileCarry)));
     // Row slabs of the transposed copy: the transposed product gathers w[row]; with more masked rows than an L2 holds
     // (K >= 11 or so) every gather would be an HBM access of its own (measured at K=14: 128 bytes fetched per
     // non-zero, 5.1 ms).  Sorting by (row slab, column) with 2 MB of w per slab keeps the gathers of one tile in L2;
@@ -546,12 +556,14 @@ extern "C" int kmers_hip_model_create_shard(const float *d_data, const uint64_t 
                        m->tval);
     hipLaunchKernelGGL(k_col_ptr, dim3(div_up((u64)m->n_trows + 1, 256)), dim3(256), 0, s, (const u32 *)keys_out.as<u32>(),
                        m->nnz, m->n_trows, m->cptr);
-    MD_CHECK(hipMalloc((void **)&m->xtiles, (size_t)m->n_tiles * sizeof(uint2)));
-    MD_CHECK(hipMalloc((void **)&m->ttiles, (size_t)m->n_tiles * sizeof(uint2)));
-    hipLaunchKernelGGL(k_tile_rows, dim3(div_up(m->n_tiles, 256)), dim3(256), 0, s, (const u32 *)m->xptr, m->n_m, m->nnz,
-                       m->n_tiles, m->xtiles);
-    hipLaunchKernelGGL(k_tile_rows, dim3(div_up(m->n_tiles, 256)), dim3(256), 0, s, (const u32 *)m->cptr, m->n_trows, m->nnz,
-                       m->n_tiles, m->ttiles);
+    m->t_nt = (m->nnz / m->n_trows >= SP_LONG_ROWS) ? SP_NT_LONG : SP_NT_SHORT;
+    m->t_tiles = div_up(m->nnz, m->t_nt * SP_IPT);
+    MD_CHECK(hipMalloc((void **)&m->xtiles, (size_t)m->x_tiles * sizeof(uint2)));
+    MD_CHECK(hipMalloc((void **)&m->ttiles, (size_t)m->t_tiles * sizeof(uint2)));
+    hipLaunchKernelGGL(k_tile_rows, dim3(div_up(m->x_tiles, 256)), dim3(256), 0, s, (const u32 *)m->xptr, m->n_m, m->nnz,
+                       m->x_tiles, m->x_nt * SP_IPT, m->xtiles);
+    hipLaunchKernelGGL(k_tile_rows, dim3(div_up(m->t_tiles, 256)), dim3(256), 0, s, (const u32 *)m->cptr, m->n_trows, m->nnz,
+                       m->t_tiles, m->t_nt * SP_IPT, m->ttiles);
     MD_CHECK(hipGetLastError());
     MD_CHECK(hipMemcpyAsync(h_stats, stats.p, 24, hipMemcpyDeviceToHost, s));
     MD_CHECK(hipStreamSynchronize(s));
@@ -594,10 +606,16 @@ static int spmv(const kmers_model *m, const u32 *ptr, const u32 *idx, const floa
         MD_CHECK(hipMemsetAsync(out, 0, (size_t)n * sizeof(OutT), s));
         return KMERS_OK;
     }
-    hipLaunchKernelGGL((k_spmv<WHICH, OutT>), dim3(div_up(m->n_tiles, SP_XCDS) * SP_XCDS), dim3(SP_NT), 0, s, ptr, idx, val, vec,
-                       tiles, n, m->nnz, m->n_tiles, out, m->carry);
+    const u32 nt = WHICH == 0 ? m->x_nt : m->t_nt, n_tiles = WHICH == 0 ? m->x_tiles : m->t_tiles;
+    const dim3 grid(div_up(n_tiles, SP_XCDS) * SP_XCDS);
+    if (nt == SP_NT_LONG)
+        hipLaunchKernelGGL((k_spmv<WHICH, OutT, SP_NT_LONG>), grid, dim3(SP_NT_LONG), 0, s, ptr, idx, val, vec, tiles, n, m->nnz,
+                           n_tiles, out, m->carry);
+    else
+        hipLaunchKernelGGL((k_spmv<WHICH, OutT, SP_NT_SHORT>), grid, dim3(SP_NT_SHORT), 0, s, ptr, idx, val, vec, tiles, n, m->nnz,
+                           n_tiles, out, m->carry);
     marks.mark(label);
-    hipLaunchKernelGGL(k_spmv_fixup<OutT>, dim3(div_up(m->n_tiles, 256)), dim3(256), 0, s, (const TileCarry *)m->carry, m->n_tiles,
+    hipLaunchKernelGGL(k_spmv_fixup<OutT>, dim3(div_up(n_tiles, 256)), dim3(256), 0, s, (const TileCarry *)m->carry, n_tiles,
                        out);
     marks.mark("k_spmv_fixup");
     MD_CHECK(hipGetLastError());
