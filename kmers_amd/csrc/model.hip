@@ -14,7 +14,7 @@
 // by (row slab, column), 2 MB of w per slab, so that its gathers stay in L2 when there are millions of masked rows;
 // it is made once per model with rocPRIM's stable radix sort (a set-up step, not the hot loop).
 //
-// k_spmv splits the NON-ZEROS evenly (2048 per workgroup, 8 consecutive ones per thread), whatever the row lengths
+// k_spmv splits the NON-ZEROS evenly (2048 or 8192 per workgroup, 8 consecutive ones per thread), whatever the row lengths
 // are (K=8: ~4000 per row; K=14: 1-2 per row, many empty rows): a thread walks its 8 products along the row
 // pointers, writes rows that end inside its range, and hands the open row's partial sum to its successors through a
 // segmented scan over the workgroup; a row that started in an earlier workgroup is finished by k_spmv_fixup from
