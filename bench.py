@@ -208,7 +208,8 @@ def bench_model(args, K, dev, rank, world, fence):
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 in, f64 accumulate", "data": "synthetic",
         "config": {"workload": f"logp_grad K={K}: X of {T} isoforms / {xs.n_bases / 1e6:.0f} Mbases, y of {args.reads} "
-                               f"simulated 100 bp reads per GPU ({args.workload}; column shards, xtheta all-reduced)",
+                               f"simulated 100 bp reads per GPU ({args.workload}"
+                               + ("; column shards, xtheta all-reduced)" if world > 1 else ")"),
                    "K": K, "nnz_x": nnz_x, "masked_rows": n_m, "nnz_xnnz": nnz, "val": val,
                    "model_setup_s": round(setup_s, 3), "parallelism": f"column-shards{world}"},
         "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
