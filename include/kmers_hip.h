@@ -13,6 +13,8 @@
  *   device X      kmers_hip_build_x  packed store -> CSR (data,row_ind,col_ind)
  *                                    (replaces collect_kmers/fill_indices_coo :218-238 and to_csr :77-169)
  *   device model  kmers_hip_model_*  X and y in HBM -> logp_grad's two sparse products (kmerexpr/utils.py:76-108)
+ *   device reads  kmers_hip_simulate_reads  transcriptome store + (isoform, start) per read -> reads store
+ *                                    (kmerexpr/simulate_reads.py:111-121)
  */
 #ifndef KMERS_HIP_H
 #define KMERS_HIP_H
@@ -189,6 +191,28 @@ int kmers_hip_model_read(const kmers_model *m, int what, void *host_dst);
  * Synchronises `stream` (val is read back).  Calls on one model must not overlap. */
 int kmers_hip_model_logp_grad(kmers_model *m, const float *d_theta, int nograd, double *val_out, float *d_grad,
                               void *stream);
+
+/* ---- simulated reads straight into a packed store ------------------------------------ */
+
+/* The copying step of the reference's simulate_reads (kmerexpr/simulate_reads.py:111-121: read n = L bases of isoform
+ * iso[n] from start[n]) on the device: the transcriptome store (kmers_store_ingest, KMERS_MODE_X with the same L, so
+ * that its records are the reference's isoform list) in, a reads store out -- read n at positions
+ * [n (L + 1), n (L + 1) + L) plus one separator, the layout kmers_hip_count_y takes with n_pos = n_reads (L + 1).
+ * Output arrays: at least n_pos / 16 + 4 and n_pos / 32 + 4 words (KMERS_ERR_WORKSPACE), fully written (padding
+ * zeroed).  An isoform index >= n_rec or a start with start + L > the record's length gives KMERS_ERR_BAD_ARG (that
+ * read is left empty, nothing is read out of bounds).  Synchronises `stream`. */
+int kmers_hip_simulate_reads(const uint32_t *d_bases, const uint32_t *d_valid, const uint64_t *d_rec_start,
+                             uint64_t n_rec, const uint32_t *d_iso, const uint32_t *d_start, uint64_t n_reads, uint32_t L,
+                             uint32_t *d_out_bases, size_t out_bases_words, uint32_t *d_out_valid,
+                             size_t out_valid_words, void *stream);
+
+/* Host: the reference's per-read `start = np.random.choice(len(seq) - L + 1)` (simulate_reads.py:116) replayed over a
+ * block of raw MT19937 32-bit outputs (np.random.randint(0, 2**32, dtype=uint32) on the same legacy stream): numpy's
+ * scalar choice(n) masks successive outputs with the smallest 2^k - 1 >= n - 1 and rejects values above n - 1; n == 1
+ * draws nothing.  n_choices[i] = len_i - L + 1.  Stops early when the block runs out: *reads_done reads are final,
+ * *raw_used outputs were consumed by them (the caller continues with the unused outputs followed by a new block). */
+int kmers_sim_starts(const uint32_t *raw, uint64_t n_raw, const uint32_t *n_choices, uint64_t n, uint32_t *start_out,
+                     uint64_t *reads_done, uint64_t *raw_used);
 
 /* logp_grad in two steps, for column shards: d_xtheta f32[n_masked] (caller's buffer) = this shard's xnnz.theta
  * (asynchronous); the caller sums the shards' buffers (one all-reduce over RCCL: the path's only exchange step);

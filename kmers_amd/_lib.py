@@ -93,6 +93,11 @@ def handle():
     lib.kmers_npz_write_csr.argtypes = [C.c_char_p, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64]
     lib.kmers_hip_model_create.restype = C.c_int
     lib.kmers_hip_model_create.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp, C.POINTER(vp)]
+    lib.kmers_hip_simulate_reads.restype = C.c_int
+    lib.kmers_hip_simulate_reads.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.c_uint32, vp, C.c_size_t, vp,
+                                             C.c_size_t, vp]
+    lib.kmers_sim_starts.restype = C.c_int
+    lib.kmers_sim_starts.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.kmers_hip_model_create_shard.restype = C.c_int
     lib.kmers_hip_model_create_shard.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, vp, vp, C.POINTER(vp)]
     lib.kmers_hip_model_xtheta_into.restype = C.c_int

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libkmers.so")
-SOURCES = ["kernels.hip", "model.hip", "ingest.cpp", "libkmers.cpp", "npz.cpp"]
+SOURCES = ["kernels.hip", "model.hip", "simreads.hip", "ingest.cpp", "libkmers.cpp", "npz.cpp"]
 HEADERS = [os.path.join(CSRC, h) for h in ("kernels.hpp", "store.hpp")] + \
           [os.path.join(ROOT, "include", h) for h in ("libkmers.h", "kmers_hip.h")]
 

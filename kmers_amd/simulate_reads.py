@@ -1,0 +1,78 @@
+"""`simulate_reads` of the reference (kmerexpr/simulate_reads.py:54-122) with the reads written straight into a packed
+store in HBM instead of a FASTA file.
+
+Every random choice is the reference's, bit for bit: the same legacy numpy calls in the same order for psi
+(np.random.seed(42), np.random.dirichlet, :55,:96) and the isoform of every read (np.random.choice(T, N, p), :105), and
+the same MT19937 stream continued for the per-read starts (np.random.choice(len - L + 1), :116, replayed in C by
+kmers_sim_starts instead of N Python-level calls).  Only the copying of the L bases of each read runs on the GPU
+(kmers_hip_simulate_reads).  The isoform list is the reference's: non-PREDICTED records of at least L bases, which is
+also the column rule of fasta_to_kmers_csr (a Store in MODE_X with the same L)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .store import MODE_X, DeviceStore, Store
+
+
+def length_adjustment(psi, lengths):
+    """reference simulate_reads.py:42-45"""
+    theta = psi * lengths
+    return theta / theta.sum()
+
+
+def length_adjustment_inverse(theta, lengths):
+    """reference simulate_reads.py:48-51"""
+    psi = theta / lengths
+    return psi / psi.sum()
+
+
+def sample_reads(rec_lengths, N, L, alpha):
+    """The reference's random choices for isoforms of the given lengths (all >= L): returns
+    dict(psi, theta_true, theta_sampled, lengths, iso_sampled int64[N], starts uint32[N])."""
+    lib = _lib.handle()
+    np.random.seed(42)                                        # :55
+    T = len(rec_lengths)
+    lengths = np.asarray(rec_lengths, dtype=np.int64) - L + 1    # :91,:98
+    assert T > 0 and lengths.min() >= 1
+    psi = np.random.dirichlet(alpha * np.ones(T))             # :95-96
+    theta_true = length_adjustment(psi, lengths)              # :101
+    iso_sampled = np.random.choice(T, size=N, replace=True, p=theta_true)    # :105
+    theta_sampled = np.bincount(iso_sampled, minlength=T) / N                # :107-108
+    # :116, N times: start = np.random.choice(len(seq) - L + 1), replayed over raw 32-bit outputs of the same stream
+    n_choices = np.ascontiguousarray(lengths[iso_sampled], dtype=np.uint32)
+    starts = np.empty(N, np.uint32)
+    done, left = 0, np.empty(0, np.uint32)
+    while done < N:
+        fresh = np.random.randint(0, 2 ** 32, size=2 * (N - done) + 1024, dtype=np.uint32)
+        raw = np.concatenate([left, fresh]) if left.size else fresh
+        rd, ru = C.c_uint64(0), C.c_uint64(0)
+        rc = lib.kmers_sim_starts(raw.ctypes.data, raw.size, n_choices[done:].ctypes.data, N - done,
+                                  starts[done:].ctypes.data, C.byref(rd), C.byref(ru))
+        _lib.check(rc, "kmers_sim_starts")
+        done += int(rd.value)
+        left = raw[int(ru.value):]
+    return dict(psi=psi, theta_true=theta_true, theta_sampled=theta_sampled, lengths=lengths, iso_sampled=iso_sampled,
+                starts=starts)
+
+
+def simulate_reads_device(N, L, alpha, ISO_FILE, device="cuda"):
+    """The reads of simulate_reads(problem(N, L, alpha), ..., ISO_FILE) as a DeviceStore (count_y-ready), plus the
+    dict of sample_reads (what the reference saves with save_simulation_parameters / save_lengths, :109-110)."""
+    import torch
+    lib = _lib.handle()
+    st = Store(ISO_FILE, MODE_X, L=L)
+    rs = st.rec_start.astype(np.int64)
+    info = sample_reads(np.diff(rs) - 1, N, L, alpha)
+    ds = st.to_device(device)
+    dev = ds.device
+    iso = torch.from_numpy(info["iso_sampled"].astype(np.uint32).view(np.int32)).to(dev)
+    starts = torch.from_numpy(info["starts"].view(np.int32)).to(dev)
+    n_pos = N * (L + 1)
+    out_bases = torch.empty((n_pos + 15) // 16 + 4, dtype=torch.int32, device=dev)
+    out_valid = torch.empty((n_pos + 31) // 32 + 4, dtype=torch.int32, device=dev)
+    rc = lib.kmers_hip_simulate_reads(ds.bases.data_ptr(), ds.valid.data_ptr(), ds.rec_start.data_ptr(), st.n_rec,
+                                      iso.data_ptr(), starts.data_ptr(), N, L, out_bases.data_ptr(), out_bases.numel(),
+                                      out_valid.data_ptr(), out_valid.numel(), None)
+    _lib.check(rc, "kmers_hip_simulate_reads")
+    return DeviceStore.from_tensors(out_bases, out_valid, n_pos, N), info

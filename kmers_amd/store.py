@@ -86,6 +86,17 @@ class DeviceStore:
         self.valid = torch.from_numpy(store.valid.view(np.int32).copy()).to(self.device)
         self.rec_start = torch.from_numpy(store.rec_start.view(np.int64).copy()).to(self.device)
 
+    @classmethod
+    def from_tensors(cls, bases, valid, n_pos, n_rec, rec_start=None):
+        """A device store whose arrays were produced on the GPU (kmers_hip_simulate_reads): no host Store behind it.
+        Enough for count_y; build_x needs rec_start."""
+        self = cls.__new__(cls)
+        self._lib = _lib.handle()
+        self.n_pos, self.n_rec, self.first_rec, self.n_rec_total = int(n_pos), int(n_rec), 0, int(n_rec)
+        self.device = bases.device
+        self.bases, self.valid, self.rec_start = bases, valid, rec_start
+        return self
+
     def y_workspace(self, K, nbytes=None):
         """Scratch for count_y at K >= 9 (None for K <= 8); keep it across repeated counts."""
         import torch
