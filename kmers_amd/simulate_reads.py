@@ -56,9 +56,11 @@ def sample_reads(rec_lengths, N, L, alpha):
                 starts=starts)
 
 
-def simulate_reads_device(N, L, alpha, ISO_FILE, device="cuda"):
+def simulate_reads_device(N, L, alpha, ISO_FILE, device="cuda", shard=0, n_shards=1):
     """The reads of simulate_reads(problem(N, L, alpha), ..., ISO_FILE) as a DeviceStore (count_y-ready), plus the
-    dict of sample_reads (what the reference saves with save_simulation_parameters / save_lengths, :109-110)."""
+    dict of sample_reads (what the reference saves with save_simulation_parameters / save_lengths, :109-110).
+    Multi-GPU: every rank makes all N choices (the random stream is serial by definition) and materialises only reads
+    [shard N / n_shards, (shard + 1) N / n_shards); the histograms are then summed with one all-reduce."""
     import torch
     lib = _lib.handle()
     st = Store(ISO_FILE, MODE_X, L=L)
@@ -66,8 +68,10 @@ def simulate_reads_device(N, L, alpha, ISO_FILE, device="cuda"):
     info = sample_reads(np.diff(rs) - 1, N, L, alpha)
     ds = st.to_device(device)
     dev = ds.device
-    iso = torch.from_numpy(info["iso_sampled"].astype(np.uint32).view(np.int32)).to(dev)
-    starts = torch.from_numpy(info["starts"].view(np.int32)).to(dev)
+    lo, hi = shard * N // n_shards, (shard + 1) * N // n_shards
+    iso = torch.from_numpy(info["iso_sampled"][lo:hi].astype(np.uint32).view(np.int32)).to(dev)
+    starts = torch.from_numpy(info["starts"][lo:hi].copy().view(np.int32)).to(dev)
+    N = hi - lo
     n_pos = N * (L + 1)
     out_bases = torch.empty((n_pos + 15) // 16 + 4, dtype=torch.int32, device=dev)
     out_valid = torch.empty((n_pos + 31) // 32 + 4, dtype=torch.int32, device=dev)

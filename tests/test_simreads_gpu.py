@@ -81,3 +81,17 @@ def test_bad_isoform_or_start_is_rejected(iso):
     s[3] = lens[0] - L + 1
     assert run(good_iso, s) == -12
     assert run(good_iso, np.zeros(N), nb=ob.numel() - 5) == -14
+
+
+def test_shards_add_up(iso):
+    """Reads split over ranks: the shard stores' histograms sum to the whole one."""
+    from kmers_amd.simulate_reads import simulate_reads_device
+    N, L, K = 3001, 60, 9
+    whole, _ = simulate_reads_device(N, L, 0.3, iso)
+    want = whole.count_y(K)
+    got = None
+    for r in range(3):
+        part, info = simulate_reads_device(N, L, 0.3, iso, shard=r, n_shards=3)
+        assert info["iso_sampled"].shape[0] == N
+        got = part.count_y(K, counts=got)
+    assert bool((got == want).all())
