@@ -53,22 +53,35 @@ __global__ __launch_bounds__(256) void k_sim_reads(const u32 *__restrict__ bases
         ok = true;
     };
     open_read();
-    u32 w0 = 0, w1 = 0, v = 0;
-    for (u32 j = 0; j < 32 && p < n_pos_out; ++j, ++p) {
+    // The 32 positions are copied in pieces of up to 16 that cross neither a read boundary nor an output word: a
+    // piece's bases are a bit-field of two consecutive source words, its validity bits of two validity words (both
+    // source arrays carry 4 words of padding).
+    u32 w[2] = {0u, 0u}, v = 0;
+    u32 j = 0;  // position inside this thread's 32
+    while (j < 32 && p < n_pos_out) {
+        u32 len = 16 - (j & 15);                       // to the end of the output word
+        if (o < L) len = min(len, L - o);              // to the end of the read's bases
+        else len = 1;                                  // the separator
+        len = (u32)min((u64)len, n_pos_out - p);
         if (o < L && ok) {
             const u64 s = src0 + o;
-            const u32 code = (bases[s >> 4] >> (30 - 2 * (u32)(s & 15))) & 3u;
-            const u32 bit = (valid[s >> 5] >> (u32)(s & 31)) & 1u;
-            if (j < 16) w0 |= code << (30 - 2 * j);
-            else w1 |= code << (30 - 2 * (j - 16));
-            v |= bit << j;
+            const u64 b64 = ((u64)bases[s >> 4] << 32) | bases[(s >> 4) + 1];
+            const u32 field = (u32)((b64 << (2 * (u32)(s & 15))) >> (64 - 2 * len));      // len bases, right-aligned
+            w[j >> 4] |= field << (32 - 2 * ((j & 15) + len));
+            const u64 v64 = (u64)valid[s >> 5] | ((u64)valid[(s >> 5) + 1] << 32);
+            const u32 bits = (u32)(v64 >> (u32)(s & 31)) & (len == 32 ? 0xFFFFFFFFu : ((1u << len) - 1u));
+            v |= bits << j;
         }
-        if (++o == L + 1) {
+        j += len;
+        p += len;
+        o += len;
+        if (o == L + 1) {
             o = 0;
             ++n;
             open_read();
         }
     }
+    const u32 w0 = w[0], w1 = w[1];
     if (2 * g < out_bases_words) out_bases[2 * g] = w0;
     if (2 * g + 1 < out_bases_words) out_bases[2 * g + 1] = w1;
     if (g < out_valid_words) out_valid[g] = v;
