@@ -1,12 +1,12 @@
 """kmers_amd.simulate_reads.sample_reads (numpy's legacy calls + the C replay of the per-read starts) against the
-restated reference simulator (oracle/simulate_reads.py): identical psi, theta, isoforms and starts."""
+restated reference simulator (oracle/reads_oracle.py): identical psi, theta, isoforms and starts."""
 import os
 
 import numpy as np
 import pytest
 
 from kmers_amd import synth
-from oracle import simulate_reads as orc
+from oracle import reads_oracle as orc
 from tests import kmtest
 
 

@@ -1,11 +1,11 @@
 """reads simulated straight into HBM (kmers_hip_simulate_reads) against the reads FILE the
-restated reference simulator writes (oracle/simulate_reads.py, reference kmerexpr/simulate_reads.py:54-122): the same
+restated reference simulator writes (oracle/reads_oracle.py, reference kmerexpr/simulate_reads.py:54-122): the same
 read sequences, hence the same y -- bit-exact.  Needs a real MI355X: run with -m gpu."""
 import numpy as np
 import pytest
 
 from kmers_amd import synth
-from oracle import simulate_reads as orc
+from oracle import reads_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
