@@ -188,7 +188,8 @@ int kmers_hip_model_read(const kmers_model *m, int what, void *host_dst);
  * Sums are accumulated in float64 and rounded to float32 once (the reference's MKL float32 products round per
  * operation), in a fixed order: the same inputs give the same bits on every call.  The (beta - 1) terms (:94-96,
  * :104-106) are O(n_cols) arithmetic on the caller's theta and are not computed here.
- * Synchronises `stream` (val is read back).  Calls on one model must not overlap. */
+ * Synchronises `stream` (val is read back).  Calls on one model must not overlap, and the model's device must be
+ * the current one (KMERS_ERR_BAD_ARG otherwise). */
 int kmers_hip_model_logp_grad(kmers_model *m, const float *d_theta, int nograd, double *val_out, float *d_grad,
                               void *stream);
 

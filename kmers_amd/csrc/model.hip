@@ -628,6 +628,12 @@ extern "C" int kmers_hip_model_create(const float *d_data, const uint64_t *d_col
     return kmers_hip_model_create_shard(d_data, d_col_ind, d_row_ind, n_rows, 0, n_cols, d_y, stream, out);
 }
 
+// the model's memory lives on the device that was current when it was made
+static bool on_models_device(const kmers_model *m) {
+    int dev = -1;
+    return hipGetDevice(&dev) == hipSuccess && dev == m->device;
+}
+
 // phase 1: xtheta = xnnz . theta (asynchronous)
 static int phase_xtheta(kmers_model *m, const float *d_theta, float *d_xtheta, hipStream_t s, Marks &marks) {
     return spmv<0>(m, m->xptr, m->xcol, m->xval, d_theta, m->xtiles, m->n_m, d_xtheta, s, marks, "k_spmv<x.theta>");
@@ -665,7 +671,7 @@ static int phase_grad(kmers_model *m, const float *d_xtheta, int nograd, double 
 
 extern "C" int kmers_hip_model_logp_grad(kmers_model *m, const float *d_theta, int nograd, double *val_out, float *d_grad,
                                          void *stream) {
-    if (!m || !d_theta || !val_out || (!nograd && !d_grad)) return KMERS_ERR_BAD_ARG;
+    if (!m || !d_theta || !val_out || (!nograd && !d_grad) || !on_models_device(m)) return KMERS_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     Marks marks(s);
     const int rc = phase_xtheta(m, d_theta, m->xtheta, s, marks);
@@ -674,14 +680,15 @@ extern "C" int kmers_hip_model_logp_grad(kmers_model *m, const float *d_theta, i
 }
 
 extern "C" int kmers_hip_model_xtheta_into(kmers_model *m, const float *d_theta, float *d_xtheta, void *stream) {
-    if (!m || !d_theta || !d_xtheta) return KMERS_ERR_BAD_ARG;
+    if (!m || !d_theta || !d_xtheta || !on_models_device(m)) return KMERS_ERR_BAD_ARG;
     Marks marks((hipStream_t)stream, false);  // asynchronous: nothing to read the events after
     return phase_xtheta(m, d_theta, d_xtheta, (hipStream_t)stream, marks);
 }
 
 extern "C" int kmers_hip_model_grad_from(kmers_model *m, const float *d_xtheta, int nograd, double *val_out, float *d_grad,
                                          void *stream) {
-    if (!m || !d_xtheta || ((uintptr_t)d_xtheta & 15) || !val_out || (!nograd && !d_grad)) return KMERS_ERR_BAD_ARG;
+    if (!m || !d_xtheta || ((uintptr_t)d_xtheta & 15) || !val_out || (!nograd && !d_grad) || !on_models_device(m))
+        return KMERS_ERR_BAD_ARG;
     Marks marks((hipStream_t)stream);
     return phase_grad(m, d_xtheta, nograd, val_out, d_grad, (hipStream_t)stream, marks);
 }
