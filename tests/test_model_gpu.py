@@ -237,3 +237,56 @@ def test_sharded_model_rehearsal_two_ranks_one_gpu(oracle, tmp_path):
     iso = os.path.join(kmtest.INP, "syn_small.fsa")
     res = _run_model_workers("gpu", 2, iso, iso, 10, str(tmp_path / "m"))
     check_sharded_model(oracle, res, iso, iso, 10)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_random_matrices(seed, monkeypatch):
+    """Random CSR matrices of many shapes (rows of thousands of non-zeros that span tiles, runs of empty rows in
+    front, inside and behind, single-entry rows, empty columns; 256- and 1024-thread products; with and without row
+    slabs) against the oracle."""
+    from kmers_amd.model import DeviceModel
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    n_rows = int(rng.choice([7, 300, 5000, 40000]))
+    n_cols = int(rng.choice([1, 9, 700, 6000]))
+    kind = seed % 4
+    if kind == 0:        # long rows
+        lens = rng.integers(0, n_cols + 1, n_rows)
+    elif kind == 1:      # short rows, many empty
+        lens = np.minimum(rng.geometric(0.5, n_rows) - 1, n_cols)
+    elif kind == 2:      # a few very long rows among empty ones
+        lens = np.zeros(n_rows, np.int64)
+        hot = rng.choice(n_rows, size=max(1, n_rows // 50), replace=False)
+        lens[hot] = n_cols
+    else:                # power law
+        lens = np.minimum((rng.pareto(1.0, n_rows) * 2).astype(np.int64), n_cols)
+    lens[: n_rows // 10] = 0                                  # empty rows in front
+    if seed % 3 == 0:
+        lens[-(n_rows // 7 + 1):] = 0                          # and behind
+    lens = lens[: max(1, min(n_rows, int(3e6 // max(1, lens.max()))))] if lens.max() * n_rows > 3e6 else lens
+    n_rows = lens.shape[0]
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    indices = np.concatenate([np.sort(rng.choice(n_cols, size=int(l), replace=False)) for l in lens] + [np.zeros(0, np.int64)])
+    data = (rng.random(indptr[-1]) + 1e-3).astype(np.float32)
+    x = csr_matrix((data, indices.astype(np.int64), indptr), shape=(n_rows, n_cols))
+    y = (rng.integers(0, 4, n_rows) * (rng.random(n_rows) < 0.8)).astype(np.int32)
+    if not y.any():
+        y[rng.integers(n_rows)] = 3
+    if seed % 2:
+        monkeypatch.setenv("KMERS_MODEL_SLAB_LOG2", "8")
+    rows, xnnz, ynnz = orc.model_setup(x, y)
+    dm = DeviceModel.from_host(x, y)
+    assert np.array_equal(dm.rows(), rows) and dm.nnz == xnnz.nnz
+    theta = rng.dirichlet(np.ones(n_cols)).astype(np.float32)
+    want_val, want_grad, want_xt = orc.logp_grad_ref(theta, 1.0, xnnz, ynnz, np.ones(n_cols))
+    val, grad = dm.logp_grad(torch.from_numpy(theta).cuda())
+    np.testing.assert_allclose(dm.xtheta(), want_xt, rtol=2e-7, atol=1e-45)
+    grad = grad.cpu().numpy()
+    if np.isfinite(want_val):
+        np.testing.assert_allclose(val, want_val, rtol=1e-12, atol=5e-7)
+        np.testing.assert_allclose(grad, want_grad, rtol=1e-6, atol=1e-30)
+    else:
+        assert val == want_val
+        fin = np.isfinite(want_grad)
+        assert np.array_equal(np.isfinite(grad), fin)
+        np.testing.assert_allclose(grad[fin], want_grad[fin], rtol=1e-6, atol=1e-30)
