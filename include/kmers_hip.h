@@ -83,6 +83,12 @@ size_t kmers_store_valid_words(const kmers_store *s);     /* length of valid[] i
 /* Number of usable HIP devices (0 when there is none; never fails). */
 int kmers_hip_device_count(void);
 
+/* Copy a host store into caller-allocated device arrays (d_bases u32[bases_words], d_valid u32[valid_words],
+ * d_rec_start u64[n_rec + 1] or NULL) straight from the store's pinned memory: the H2D step of the file-level calls
+ * (kmers_amd/csrc/libkmers.cpp, DevStore::upload), for callers that keep the store resident.  Synchronises `stream`. */
+int kmers_hip_store_upload(const kmers_store *s, uint32_t *d_bases, uint32_t *d_valid, uint64_t *d_rec_start,
+                           void *stream);
+
 /* y: for every position p with valid[p .. p+K) all set, counts[id(p)] += 1.
  * d_counts is int32[4^K] in HBM and is ADDED to (the caller zeroes it), like the reference's histogram.
  * K <= 8: LDS-privatised histograms, asynchronous on `stream`.  K >= 9: the k-mers are partitioned by their top

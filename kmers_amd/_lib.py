@@ -76,6 +76,7 @@ def handle():
     for name in ("bases_words", "valid_words"):
         f = getattr(lib, "kmers_store_" + name)
         f.restype, f.argtypes = C.c_size_t, [vp]
+    lib.kmers_hip_store_upload.restype, lib.kmers_hip_store_upload.argtypes = C.c_int, [vp, vp, vp, vp, vp]
     lib.kmers_hip_device_count.restype, lib.kmers_hip_device_count.argtypes = C.c_int, []
     lib.kmers_hip_count_y.restype = C.c_int
     lib.kmers_hip_count_y.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_uint64, C.c_int, vp, vp]

@@ -169,9 +169,11 @@ struct RawVec {
         n += more;
         return r;
     }
-    void push(const T &v) {
+    bool push(const T &v) {  // false: no memory (the element is not stored)
         T *r = grow(1);
-        if (r) *r = v;
+        if (!r) return false;
+        *r = v;
+        return true;
     }
     size_t size() const { return n; }
     const T *begin() const { return p; }
@@ -514,8 +516,9 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
             for (size_t f = lo; f < hi; ++f) read_fastq_sequence(fnames[f], fq[f]);
         });
         for (int f = 0; f < n_files; ++f) {
-            pieces.push(Piece{fq[f].data(), fq[f].data() + fq[f].size(), (uint64_t)f, 0, fq[f].size(), false});
-            rec_len.push(fq[f].size());
+            if (!pieces.push(Piece{fq[f].data(), fq[f].data() + fq[f].size(), (uint64_t)f, 0, fq[f].size(), false}) ||
+                !rec_len.push(fq[f].size()))
+                return KMERS_ERR_NOMEM;
         }
     } else {
         std::vector<size_t> hdrs;
@@ -525,7 +528,7 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
             FileView &fv = *files[f];
             if (!fv.open(fnames[f])) {
                 if (cat) {  // reference src/libkmers.cpp:402-403: the job just returns, the column stays empty
-                    rec_len.push(0);
+                    if (!rec_len.push(0)) return KMERS_ERR_NOMEM;
                     continue;
                 }
                 return KMERS_ERR_OPEN;  // reference src/libkmers.cpp:356-357, 440-441
@@ -548,10 +551,10 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
                 for (const RecInfo &r : recs) {
                     if (r.predicted || off >= eff) continue;
                     const uint64_t take = std::min<uint64_t>(r.full_len, eff - off);
-                    if (take) pieces.push(Piece{fv.p + r.seq_off, fv.p + r.end_off, rec, off, take, true});
+                    if (take && !pieces.push(Piece{fv.p + r.seq_off, fv.p + r.end_off, rec, off, take, true})) return KMERS_ERR_NOMEM;
                     off += r.full_len;
                 }
-                rec_len.push(eff);
+                if (!rec_len.push(eff)) return KMERS_ERR_NOMEM;
             } else {
                 // kept records get consecutive numbers: count, prefix, fill -- all in parallel
                 auto kept = [&](size_t i) -> uint64_t {

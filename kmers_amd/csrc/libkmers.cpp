@@ -246,6 +246,30 @@ int build_files(int n_files, const char *fnames[], int K, int L, int mode, float
     return KMERS_OK;
 }
 
+// Every failure of a file-level call says so on stderr: the reference's own wrapper only looks for -1 and -2
+// (kmerexpr/libkmers.py:102-103, :173-176), so without this line a code <= -10 would go by unnoticed there.
+// KMERS_REFERENCE_CODES=1 folds those codes into -1, the one failure the unchanged wrapper raises on.
+int report(int rc, const char *call) {
+    if (rc == KMERS_OK) return rc;
+    const char *why = "unknown error";
+    switch (rc) {
+        case KMERS_ERR_OPEN: why = "a FASTA / FASTQ file could not be opened"; break;
+        case KMERS_ERR_MAX_NZ: why = "more non-zeros than max_size"; break;
+        case KMERS_ERR_NO_DEVICE: why = "no usable HIP device (this library has no CPU fallback); outputs were not written"; break;
+        case KMERS_ERR_HIP: why = "a HIP runtime call failed; outputs are incomplete"; break;
+        case KMERS_ERR_BAD_ARG: why = "bad argument (K outside 1..16, a null pointer, a negative count, KMERS_DEVICE out of range)"; break;
+        case KMERS_ERR_TOO_LARGE: why = "input too large for one device call (more than 2^32-65536 positions)"; break;
+        case KMERS_ERR_WORKSPACE: why = "workspace too small"; break;
+        case KMERS_ERR_NOMEM: why = "host allocation failed"; break;
+    }
+    fprintf(stderr, "libkmers: %s failed with code %d: %s\n", call, rc, why);
+    if (rc <= KMERS_ERR_NO_DEVICE) {
+        const char *e = getenv("KMERS_REFERENCE_CODES");
+        if (e && atoi(e) != 0) return KMERS_ERR_OPEN;
+    }
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -266,21 +290,23 @@ bool valid_kmer(const char *kmer, int len) {
 }
 
 int fasta_count_kmers(int n_files, const char *fnames[], int K, int *total_kmer_counts) {
-    return count_files(n_files, fnames, K, total_kmer_counts, KMERS_MODE_Y_FASTA);
+    return report(count_files(n_files, fnames, K, total_kmer_counts, KMERS_MODE_Y_FASTA), "fasta_count_kmers");
 }
 
 int fastq_gz_count_kmers(int n_files, const char *fnames[], int K, int *total_kmer_counts) {
-    return count_files(n_files, fnames, K, total_kmer_counts, KMERS_MODE_Y_FASTQ);
+    return report(count_files(n_files, fnames, K, total_kmer_counts, KMERS_MODE_Y_FASTQ), "fastq_gz_count_kmers");
 }
 
 int fasta_to_kmers_csr(int n_files, const char *fnames[], int K, int L, float *data, uint64_t *row_ind, uint64_t *col_ind,
                        uint64_t max_size, uint64_t *nnz, int *n_cols) {
-    return build_files(n_files, fnames, K, L, KMERS_MODE_X, data, row_ind, col_ind, max_size, nnz, n_cols);
+    return report(build_files(n_files, fnames, K, L, KMERS_MODE_X, data, row_ind, col_ind, max_size, nnz, n_cols),
+                  "fasta_to_kmers_csr");
 }
 
 int fasta_to_kmers_csr_cat_subseq(int n_files, const char *fnames[], int K, int L, float *data, uint64_t *row_ind,
                                   uint64_t *col_ind, uint64_t max_size, uint64_t *nnz, int *n_cols) {
-    return build_files(n_files, fnames, K, L, KMERS_MODE_X_CAT, data, row_ind, col_ind, max_size, nnz, n_cols);
+    return report(build_files(n_files, fnames, K, L, KMERS_MODE_X_CAT, data, row_ind, col_ind, max_size, nnz, n_cols),
+                  "fasta_to_kmers_csr_cat_subseq");
 }
 
 // ---- device-resident stages ----------------------------------------------------------------------------
@@ -292,6 +318,17 @@ int kmers_hip_device_count(void) {
         return 0;
     }
     return n;
+}
+
+int kmers_hip_store_upload(const kmers_store *st, uint32_t *d_bases, uint32_t *d_valid, uint64_t *d_rec_start, void *stream) {
+    if (!st || !d_bases || !d_valid) return KMERS_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    API_HIP(hipMemcpyAsync(d_bases, st->bases, st->bases_words * 4, hipMemcpyHostToDevice, s));
+    API_HIP(hipMemcpyAsync(d_valid, st->valid, st->valid_words * 4, hipMemcpyHostToDevice, s));
+    if (d_rec_start)
+        API_HIP(hipMemcpyAsync(d_rec_start, st->rec_start.data(), st->rec_start.size() * 8, hipMemcpyHostToDevice, s));
+    API_HIP(hipStreamSynchronize(s));  // the store may be freed as soon as this returns
+    return KMERS_OK;
 }
 
 int kmers_hip_count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words, uint64_t n_pos,

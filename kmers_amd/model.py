@@ -25,9 +25,10 @@ class DeviceModel:
         self.device = y.device
         self.n_rows, self.n_cols = y.numel(), int(n_cols)
         h = C.c_void_p()
-        rc = self._lib.kmers_hip_model_create_shard(data.data_ptr(), col_ind.data_ptr(), row_ind.data_ptr(), self.n_rows,
-                                                    int(first_col), self.n_cols, y.data_ptr(), _stream_ptr(stream),
-                                                    C.byref(h))
+        with torch.cuda.device(self.device):     # the C ABI allocates and launches on the CURRENT device
+            rc = self._lib.kmers_hip_model_create_shard(data.data_ptr(), col_ind.data_ptr(), row_ind.data_ptr(),
+                                                        self.n_rows, int(first_col), self.n_cols, y.data_ptr(),
+                                                        _stream_ptr(stream), C.byref(h))
         _lib.check(rc, "kmers_hip_model_create_shard")
         self._h = h
         self.n_masked = int(self._lib.kmers_hip_model_n_masked(h))
@@ -62,8 +63,9 @@ class DeviceModel:
         import torch
         assert theta.dtype == torch.float32 and theta.numel() == self.n_cols and theta.is_cuda and theta.is_contiguous()
         val = C.c_double(0.0)
-        rc = self._lib.kmers_hip_model_logp_grad(self._h, theta.data_ptr(), 1 if nograd else 0, C.byref(val),
-                                                 None if nograd else self._grad.data_ptr(), _stream_ptr(stream))
+        with torch.cuda.device(self.device):
+            rc = self._lib.kmers_hip_model_logp_grad(self._h, theta.data_ptr(), 1 if nograd else 0, C.byref(val),
+                                                     None if nograd else self._grad.data_ptr(), _stream_ptr(stream))
         _lib.check(rc, "kmers_hip_model_logp_grad")
         return val.value if nograd else (val.value, self._grad)
 
@@ -72,21 +74,26 @@ class DeviceModel:
         import torch
         assert theta.dtype == torch.float32 and theta.numel() == self.n_cols and theta.is_cuda and theta.is_contiguous()
         assert out.dtype == torch.float32 and out.numel() == self.n_masked and out.is_cuda and out.is_contiguous()
-        rc = self._lib.kmers_hip_model_xtheta_into(self._h, theta.data_ptr(), out.data_ptr(), _stream_ptr(stream))
+        with torch.cuda.device(self.device):
+            rc = self._lib.kmers_hip_model_xtheta_into(self._h, theta.data_ptr(), out.data_ptr(), _stream_ptr(stream))
         _lib.check(rc, "kmers_hip_model_xtheta_into")
         return out
 
     def grad_from(self, xtheta, nograd=False, stream=None):
         """val (and this model's gradient entries) from a given xtheta, e.g. the sum over column shards."""
+        import torch
         val = C.c_double(0.0)
-        rc = self._lib.kmers_hip_model_grad_from(self._h, xtheta.data_ptr(), 1 if nograd else 0, C.byref(val),
-                                                 None if nograd else self._grad.data_ptr(), _stream_ptr(stream))
+        with torch.cuda.device(self.device):
+            rc = self._lib.kmers_hip_model_grad_from(self._h, xtheta.data_ptr(), 1 if nograd else 0, C.byref(val),
+                                                     None if nograd else self._grad.data_ptr(), _stream_ptr(stream))
         _lib.check(rc, "kmers_hip_model_grad_from")
         return val.value if nograd else (val.value, self._grad)
 
     def _read(self, what, dtype):
+        import torch
         out = np.empty(self.n_masked, dtype)
-        _lib.check(self._lib.kmers_hip_model_read(self._h, what, out.ctypes.data), "kmers_hip_model_read")
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.kmers_hip_model_read(self._h, what, out.ctypes.data), "kmers_hip_model_read")
         return out
 
     def rows(self):

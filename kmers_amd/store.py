@@ -80,11 +80,19 @@ class DeviceStore:
         self.n_pos, self.n_rec, self.first_rec = store.n_pos, store.n_rec, store.first_rec
         self.n_rec_total = store.n_rec_total
         self.device = torch.device(device)
-        # int32 / int64 views: torch has no unsigned 32/64-bit arithmetic types, and none is needed -- these
-        # tensors are only device allocations whose addresses go to the C ABI
-        self.bases = torch.from_numpy(store.bases.view(np.int32).copy()).to(self.device)
-        self.valid = torch.from_numpy(store.valid.view(np.int32).copy()).to(self.device)
-        self.rec_start = torch.from_numpy(store.rec_start.view(np.int64).copy()).to(self.device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        # int32 / int64 tensors: torch has no unsigned 32/64-bit arithmetic types, and none is needed -- these
+        # tensors are only device allocations whose addresses go to the C ABI.  The copy is the library's own
+        # hipMemcpyAsync out of the store's pinned arrays (no pageable staging copy on the way).
+        lib = self._lib
+        nb, nv = int(lib.kmers_store_bases_words(store._h)), int(lib.kmers_store_valid_words(store._h))
+        self.bases = torch.empty(nb, dtype=torch.int32, device=self.device)
+        self.valid = torch.empty(nv, dtype=torch.int32, device=self.device)
+        self.rec_start = torch.empty(self.n_rec + 1, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(lib.kmers_hip_store_upload(store._h, self.bases.data_ptr(), self.valid.data_ptr(),
+                                                  self.rec_start.data_ptr(), None), "kmers_hip_store_upload")
 
     @classmethod
     def from_tensors(cls, bases, valid, n_pos, n_rec, rec_start=None):
@@ -111,13 +119,19 @@ class DeviceStore:
         if counts is None:
             counts = torch.zeros(4 ** K, dtype=torch.int32, device=self.device)
         assert counts.dtype == torch.int32 and counts.numel() == 4 ** K and counts.is_contiguous()
-        if workspace is None:
+        own_ws = workspace is None
+        if own_ws:
             workspace = self.y_workspace(K)
-        rc = self._lib.kmers_hip_count_y_ws(self.bases.data_ptr(), self.bases.numel(), self.valid.data_ptr(),
-                                            self.valid.numel(), self.n_pos, K, counts.data_ptr(),
-                                            workspace.data_ptr() if workspace is not None else None,
-                                            workspace.numel() if workspace is not None else 0, _stream_ptr(stream))
+        with torch.cuda.device(self.device):          # the C ABI launches on the CURRENT device
+            rc = self._lib.kmers_hip_count_y_ws(self.bases.data_ptr(), self.bases.numel(), self.valid.data_ptr(),
+                                                self.valid.numel(), self.n_pos, K, counts.data_ptr(),
+                                                workspace.data_ptr() if workspace is not None else None,
+                                                workspace.numel() if workspace is not None else 0, _stream_ptr(stream))
         _lib.check(rc, "kmers_hip_count_y_ws")
+        if own_ws and workspace is not None and stream is not None:
+            # the kernels on `stream` still use the scratch after this returns: keep the caching allocator from
+            # handing the block out on another stream before they are done (callers who pass a workspace own it)
+            workspace.record_stream(stream)
         return counts
 
     def x_buffers(self, K, max_nz):
@@ -134,14 +148,19 @@ class DeviceStore:
 
     def build_x(self, buf, stream=None):
         """CSR of X for this store into `buf` (from x_buffers).  Returns nnz.  Synchronises the stream."""
+        import torch
         nnz = C.c_uint64(0)
-        rc = self._lib.kmers_hip_build_x(self.bases.data_ptr(), self.bases.numel(), self.valid.data_ptr(),
+        with torch.cuda.device(self.device):
+            rc = self._call_build_x(buf, nnz, stream)
+        _lib.check(rc, "kmers_hip_build_x")
+        return int(nnz.value)
+
+    def _call_build_x(self, buf, nnz, stream):
+        return self._lib.kmers_hip_build_x(self.bases.data_ptr(), self.bases.numel(), self.valid.data_ptr(),
                                          self.valid.numel(), self.rec_start.data_ptr(), self.n_pos, self.n_rec,
                                          self.first_rec, buf["K"], buf["data"].data_ptr(), buf["col_ind"].data_ptr(),
                                          buf["row_ind"].data_ptr(), buf["max_nz"], buf["workspace"].data_ptr(),
                                          buf["workspace"].numel(), C.byref(nnz), _stream_ptr(stream))
-        _lib.check(rc, "kmers_hip_build_x")
-        return int(nnz.value)
 
 
 def _stream_ptr(stream):

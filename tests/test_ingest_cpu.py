@@ -170,3 +170,50 @@ def test_many_small_records(tmp_path, mode):
         merged += sh.sequences()
         first += sh.n_rec
     assert merged == want
+
+
+REF_WRAPPER = "/root/reference/kmerexpr/libkmers.py"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_WRAPPER), reason="the reference tree exists in the build container only")
+def test_unmodified_reference_wrapper_binds_and_failures_are_loud(tmp_path):
+    """The zero-change route: the reference's own kmerexpr/libkmers.py (loaded by path, unmodified) on the product .so.
+    All six symbols bind with the reference's argtypes (kmerexpr/libkmers.py:37-74).  Without a GPU the file-level calls
+    cannot compute: the failure is one line on stderr, and with KMERS_REFERENCE_CODES=1 the code is folded into -1 so
+    that the unchanged wrapper raises (it only looks for -1 / -2, :102-103, :173-176).  Runs in a child process: the
+    wrapper finds the library relative to the working directory."""
+    import subprocess
+    import sys
+    lib_dir = tmp_path / "lib"
+    lib_dir.mkdir()
+    os.symlink(kmtest.PRODUCT_SO, lib_dir / "libkmers.so")
+    fsa = os.path.join(kmtest.INP, "ref_test1.fsa")
+    script = f"""
+import importlib.util, sys
+import numpy as np
+spec = importlib.util.spec_from_file_location("ref_libkmers", {REF_WRAPPER!r})
+m = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(m)
+for name in ("fasta_count_kmers", "fastq_gz_count_kmers", "fasta_to_kmers_csr", "fasta_to_kmers_csr_cat_subseq"):
+    assert getattr(m, "_" + name).argtypes is not None, name       # bound by the wrapper with its own argtypes
+assert m._libkmers.kmer_to_id(b"ACGT", 4) == 27 and m._libkmers.valid_kmer(b"ACGT", 4)   # the two it leaves unbound
+try:
+    y = m.fasta_count_kmers({fsa!r}, 1)
+    print("Y", int(y.sum()))
+except RuntimeError as e:
+    print("RAISED", e)
+"""
+    env = dict(os.environ, KMERS_NO_TORCH="1")
+    env.pop("KMERS_REFERENCE_CODES", None)
+    have_gpu = _lib.handle().kmers_hip_device_count() > 0
+    r = subprocess.run([sys.executable, "-c", script], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    if have_gpu:
+        assert "Y 10" in r.stdout              # test1.fsa: ACGT + ACGTAA... (10 bases)
+        return
+    assert "Y 0" in r.stdout                   # the unchanged wrapper does not look at -10 ...
+    assert "libkmers: fasta_count_kmers failed with code -10" in r.stderr and "no usable HIP device" in r.stderr
+    env["KMERS_REFERENCE_CODES"] = "1"         # ... unless the codes are folded into the one it raises on
+    r = subprocess.run([sys.executable, "-c", script], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "RAISED" in r.stdout and "no usable HIP device" in r.stderr
