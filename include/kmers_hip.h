@@ -109,6 +109,17 @@ int kmers_hip_count_y_ws(const uint32_t *d_bases, size_t bases_words, const uint
                          uint64_t n_pos, int K, int32_t *d_counts, void *d_workspace, size_t workspace_bytes,
                          void *stream);
 
+/* kmers_hip_count_y for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  Same kernels and same result as kmers_hip_count_y_ws, but
+ * the scratch of the K >= 9 path is a 32 MiB array that lives inside the library's code object on every GPU it runs on
+ * (looked up once per device on the first call there); the store is worked through in chunks that fit it.  The call
+ * allocates nothing (no hipMalloc / hipFree / events), is asynchronous on `stream`, and takes at most 2^28 positions
+ * (KMERS_ERR_TOO_LARGE with a message above that).  All calls on one GPU share the one array: calls that overlap
+ * there (two streams, two threads) race -- serialise them. */
+#define KMERS_STATIC_MAX_POS (1ull << 28)
+int kmers_hip_count_y_static(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words,
+                             uint64_t n_pos, int K, int32_t *d_counts, void *stream);
+
 /* Bytes of scratch HBM kmers_hip_build_x needs for a store of n_pos positions / n_rec records. */
 size_t kmers_hip_x_workspace_bytes(uint64_t n_pos, uint64_t n_rec, int K);
 

@@ -83,6 +83,8 @@ def handle():
     lib.kmers_hip_y_workspace_bytes.restype, lib.kmers_hip_y_workspace_bytes.argtypes = C.c_size_t, [C.c_uint64, C.c_int]
     lib.kmers_hip_count_y_ws.restype = C.c_int
     lib.kmers_hip_count_y_ws.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_uint64, C.c_int, vp, vp, C.c_size_t, vp]
+    lib.kmers_hip_count_y_static.restype = C.c_int
+    lib.kmers_hip_count_y_static.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_uint64, C.c_int, vp, vp]
     lib.kmers_hip_x_workspace_bytes.restype = C.c_size_t
     lib.kmers_hip_x_workspace_bytes.argtypes = [C.c_uint64, C.c_uint64, C.c_int]
     lib.kmers_hip_build_x.restype = C.c_int

@@ -1566,7 +1566,7 @@ struct PhaseTimer {
     bool on;
     std::vector<hipEvent_t> ev;
     std::vector<const char *> label;
-    explicit PhaseTimer(hipStream_t s_) : s(s_), on(g_prof_on) { mark(nullptr); }
+    explicit PhaseTimer(hipStream_t s_, bool allowed = true) : s(s_), on(g_prof_on && allowed) { mark(nullptr); }
     void mark(const char *name) {  // closes the phase `name` (first call opens the timeline)
         if (!on) return;
         hipEvent_t e;
@@ -1740,6 +1740,30 @@ size_t y_workspace_bytes(uint64_t n_pos, int K) {
     return y_layout_for(y_default_chunk_tiles(n_pos), K).bytes;
 }
 
+// ---- the library's own scratch, for callers that cannot allocate (kmers_hip_count_y_static, include/kmers_hip.h):
+// a file-scope device array that every GPU the library runs on holds until the process ends.  In host code the
+// array's NAME is only a stand-in (passing it to a kernel compiles and then faults on the GPU): the device address
+// comes from hipGetSymbolAddress, once per device with that device current, and only that pointer is used below.
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+static std::mutex g_scratch_mu;
+static void *g_scratch_ptr[64];  // per device ordinal
+
+int static_scratch(void **ptr, size_t *bytes) {
+    int dev = -1;
+    KK_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return -12;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        KK_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return -11;
+        g_scratch_ptr[dev] = p;
+    }
+    *ptr = g_scratch_ptr[dev];
+    *bytes = STATIC_SCRATCH_BYTES;
+    return 0;
+}
+
 template <int BPB_LOG2, class ET>
 static void launch_y_sorted(uint32_t blocks, hipStream_t s, const ET *ent, const uint32_t *regions, int two_pass, int low_bits,
                             int32_t *counts, uint32_t cap, uint32_t *ovf_count, YOverflow *ovf, uint32_t ovf_cap) {
@@ -1750,11 +1774,11 @@ static void launch_y_sorted(uint32_t blocks, hipStream_t s, const ET *ent, const
 }
 
 int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words, uint64_t n_pos, int K,
-            int32_t *d_counts, void *d_ws, size_t ws_bytes, hipStream_t s) {
+            int32_t *d_counts, void *d_ws, size_t ws_bytes, hipStream_t s, bool may_profile) {
     if (n_pos == 0) return 0;
     BasesArgs a{d_bases, d_valid, nullptr, nullptr, bases_words, valid_words, n_pos, K, 0, 0};
     const uint64_t n_tiles = (n_pos + TILE - 1) / TILE;
-    PhaseTimer pt(s);
+    PhaseTimer pt(s, may_profile);  // (the per-kernel timers create HIP events: never on the no-allocation entry point)
     if (K <= 8) {
         const uint32_t n_bins = 1u << (2 * K);
         const uint64_t n_words = (n_pos + 15) / 16;

@@ -28,7 +28,13 @@ size_t y_workspace_bytes(uint64_t n_pos, int K);  // 0 for K <= 8
 // Both return 0 or a KMERS_ERR_* code (include/kmers_hip.h).  count_y needs a workspace for K >= 9 (any size from one
 // tile's worth up: a smaller one means more chunks).
 int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words, uint64_t n_pos, int K,
-            int32_t *d_counts, void *d_ws, size_t ws_bytes, hipStream_t s);
+            int32_t *d_counts, void *d_ws, size_t ws_bytes, hipStream_t s, bool may_profile = true);
+
+// The library-owned scratch of kmers_hip_count_y_static: a file-scope __device__ array in kernels.hip.  Returns its
+// address on the CURRENT device (looked up with hipGetSymbolAddress on the first call per device) and its size.
+constexpr size_t STATIC_SCRATCH_BYTES = (size_t)32 << 20;
+constexpr uint64_t STATIC_MAX_POS = 1ull << 28;   // positions per call of the no-allocation entry point
+int static_scratch(void **ptr, size_t *bytes);
 
 int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words, const uint64_t *d_rec_start,
             uint64_t n_pos, uint64_t n_rec, uint64_t first_col, int K, float *d_data, uint64_t *d_col_ind, uint64_t *d_row_ind,

@@ -359,6 +359,25 @@ int kmers_hip_count_y_ws(const uint32_t *d_bases, size_t bases_words, const uint
                        (hipStream_t)stream);
 }
 
+int kmers_hip_count_y_static(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words,
+                             uint64_t n_pos, int K, int32_t *d_counts, void *stream) {
+    if (K < 1 || K > 16 || !d_counts || (n_pos && (!d_bases || !d_valid))) return KMERS_ERR_BAD_ARG;
+    if (bases_words < (n_pos + 15) / 16 || valid_words < (n_pos + 31) / 32) return KMERS_ERR_BAD_ARG;
+    if (n_pos > kk::STATIC_MAX_POS) {
+        fprintf(stderr, "libkmers: kmers_hip_count_y_static takes at most %llu positions per call (got %llu): split the "
+                        "store or use kmers_hip_count_y_ws\n",
+                (unsigned long long)kk::STATIC_MAX_POS, (unsigned long long)n_pos);
+        return KMERS_ERR_TOO_LARGE;
+    }
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    if (K >= 9 && n_pos)  // K <= 8 counts in LDS and needs no scratch at all
+        if (int rc = kk::static_scratch(&ws, &ws_bytes)) return rc;
+    // the same kernels as kmers_hip_count_y_ws, in chunks that fit the static array; no hipMalloc, no events
+    return kk::count_y(d_bases, bases_words, d_valid, valid_words, n_pos, K, d_counts, ws, ws_bytes, (hipStream_t)stream,
+                       /*may_profile=*/false);
+}
+
 size_t kmers_hip_x_workspace_bytes(uint64_t n_pos, uint64_t n_rec, int K) {
     if (K < 1 || K > 16) return 0;
     return kk::x_workspace_bytes(n_pos, n_rec, K);
