@@ -29,10 +29,12 @@ def up_to_date():
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, verbose=False, stamps=False):
+def build(force=False, verbose=False, stamps=False, defines=(), variant=None):
     """Compile kmers_amd/lib/libkmers.so for gfx950.  Cross-compiles without a GPU.
     stamps=True builds the diagnostic variant lib/libkmers_stamps.so (in-kernel phase timers; never the product)."""
-    if stamps:
+    if variant:       # diagnostic A/B builds: lib/libkmers_<variant>.so with extra -D flags (never the product)
+        out = os.path.join(LIB_DIR, f"libkmers_{variant}.so")
+    elif stamps:
         out = os.path.join(LIB_DIR, "libkmers_stamps.so")
     else:
         out = LIB
@@ -43,6 +45,7 @@ def build(force=False, verbose=False, stamps=False):
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out]
     if stamps:
         cmd.append("-DKK_STAMPS")
+    cmd += ["-D" + d for d in defines]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-lz", "-lpthread"]
     if verbose:
@@ -52,4 +55,6 @@ def build(force=False, verbose=False, stamps=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, stamps="--stamps" in sys.argv))
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    var = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--variant=")), None)
+    print(build(force="--force" in sys.argv, verbose=True, stamps="--stamps" in sys.argv, defines=defs, variant=var))

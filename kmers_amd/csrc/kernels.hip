@@ -32,7 +32,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -1528,6 +1530,711 @@ __global__ __launch_bounds__(NT) void k_fill_tasks(uint64_t *row_ind, const Fill
 }
 
 // ------------------------------------------------------------------------------------------------------
+// X for 5 <= K <= 8: per-isoform LDS tables ("count first, then transpose")
+// ------------------------------------------------------------------------------------------------------
+//
+// What it replaces: collect_kmers + fill_indices_coo (reference src/libkmers.cpp:218-238, one unordered_map per
+// isoform) and ThreadPoolLocalData::to_csr (:77-169).  For K <= 8 all 4^K k-mers of an isoform fit in one LDS table
+// (16-bit fields: 128 KB at K = 8), so a workgroup counts an isoform's k-mers exactly as the reference's map does and
+// emits ONE entry per distinct (k-mer, isoform) with its count.  Every entry is then a CSR non-zero: its final
+// position follows from histograms alone, the last partition pass writes data / col_ind in place, and the run-length
+// reduce (k_rle) and its scan across tiles are not needed at all.
+//
+//   k_dd<false>  per isoform: first occurrences of every k-mer (a 4^K-bit LDS set) -> number of entries per
+//                (tile, low digit); valid windows per isoform (the reference's total_count)
+//   scan         -> position of the first entry of every (low digit, tile)
+//   k_dd<true>   per isoform: count in the LDS table, then every window claims its k-mer's field (a returning
+//                atomic AND that clears it): the claimer emits  high digit << 24 | (count - 1) << colbits | column
+//                into the tile's LDS staging, grouped by low digit; coalesced runs out
+//   k_hist_entries, scan          (shared with the general path: histogram of the high digit)
+//   k_row_counts, k_row_ptr       row_ind from the two scans
+//   k_final_scatter               stable partition by the high digit that writes data / col_ind directly
+//   k_fix_escapes                 counts that do not fit the entry's count field (poly-A): values patched afterwards
+//
+// Work split: workgroup w owns the isoforms that START in its range of tiles (a tile = DD_C positions of the store);
+// a tile's entries go to histogram row tile + w, so a tile shared by two workgroups (one's last isoform ends where the
+// next one's first begins) has a row per workgroup and rows stay in position order.  Isoforms are processed one after
+// the other (they share the table); the order of the entries of one isoform inside a (tile, digit) group is whatever
+// the LDS atomics hand out, which is harmless: an isoform has one entry per k-mer, and entries of different isoforms
+// never interleave.  Which TILE a k-mer's entry belongs to is the tile of its first occurrence, in both kernels
+// (tiles of an isoform are separated by barriers).
+// Fields are 16 bits: a k-mer that occurs 65536 times in ONE isoform would wrap; isoforms long enough for that count
+// with returning atomics and raise scal[6], upon which the host reruns the build on the general path.
+
+constexpr int DD_NT = 1024;          // one workgroup per CU
+constexpr int DD_W = 6;              // windows per thread and tile
+constexpr int DD_C = DD_NT * DD_W;   // positions per tile = capacity of the entry staging
+constexpr int DD_GRID = 256;
+constexpr uint32_t DD_MAX_REC = 1u << 22;   // columns fit 22 bits, so the count field has at least 2
+
+struct DDArgs {
+    const uint32_t *bases, *valid;
+    uint64_t bases_words, valid_words;
+    const uint64_t *rec_start;
+    uint32_t n_rec;
+    int K;
+    const uint32_t *wg_rec;  // [grid + 1]: first record of every workgroup
+};
+
+struct DDEscape {
+    uint32_t key, col, count;
+};
+
+// wg_rec[w] = first record that starts at or after the first position of workgroup w's tiles; wg_rec[grid] = n_rec.
+__global__ void k_dd_ranges(const uint64_t *rec_start, uint32_t n_rec, uint64_t n_pos, uint32_t grid, uint32_t *wg_rec) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > grid) return;
+    const uint64_t tiles = (n_pos + DD_C - 1) / DD_C, per = (tiles + grid - 1) / grid;
+    const uint64_t target = (uint64_t)w * per * DD_C;
+    uint32_t lo = 0, hi = n_rec;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (rec_start[mid] < target)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    wg_rec[w] = (w == grid) ? n_rec : lo;
+}
+
+struct DDWords {
+    uint32_t b0, b1, v0, v1;
+};
+// the words that hold the DD_W windows starting at p0 .. p0 + DD_W - 1 (K <= 8: 13 positions, never more than two words)
+__device__ __forceinline__ DDWords dd_fetch(const DDArgs &a, uint32_t p0) {
+    const uint64_t bw = p0 >> 4, vw = p0 >> 5;
+    DDWords x;
+    x.b0 = (bw < a.bases_words) ? a.bases[bw] : 0u;
+    x.b1 = (bw + 1 < a.bases_words) ? a.bases[bw + 1] : 0u;
+    x.v0 = (vw < a.valid_words) ? a.valid[vw] : 0u;
+    x.v1 = (vw + 1 < a.valid_words) ? a.valid[vw + 1] : 0u;
+    return x;
+}
+__device__ __forceinline__ void dd_decode(const DDWords &x, uint32_t p0, int K, uint32_t (&key)[DD_W], uint32_t &okm) {
+    const u64 B = ((u64)x.b0 << 32) | x.b1, V = ((u64)x.v1 << 32) | x.v0;
+    const uint32_t ob = p0 & 15u, ov = p0 & 31u, need = (1u << K) - 1u, mask = (1u << (2 * K)) - 1u;
+    okm = 0;
+#pragma unroll
+    for (int j = 0; j < DD_W; ++j) {
+        key[j] = (uint32_t)(B >> (64u - 2u * (ob + (uint32_t)j + (uint32_t)K))) & mask;  // shift >= 64 - 2 (15 + 5 + 8) = 8
+        const uint32_t ok = (((uint32_t)(V >> (ov + (uint32_t)j))) & need) == need;      // ov + j + K <= 44 bits
+        okm |= ok << j;
+    }
+}
+
+// The tile's packed words, staged in LDS: a thread's DD_W windows are DD_NT positions apart (see k_dd), so it reads them
+// from here rather than from two registers.
+struct DDTile {
+    uint32_t sb[DD_C / 16 + 2];
+    uint32_t sv[DD_C / 32 + 2];
+};
+constexpr int DD_TB = DD_C / 16 + 2, DD_TV = DD_C / 32 + 2;
+static_assert(DD_TB + DD_TV <= DD_NT, "one staged word per thread");
+// thread tid's word of the tile that starts at position tile_lo (a multiple of DD_C, hence of 32)
+__device__ __forceinline__ uint32_t dd_tile_fetch(const DDArgs &a, uint32_t tile_lo, uint32_t tid) {
+    if (tid < (uint32_t)DD_TB) {
+        const uint64_t bw = (uint64_t)(tile_lo >> 4) + tid;
+        return (bw < a.bases_words) ? a.bases[bw] : 0u;
+    }
+    if (tid < (uint32_t)(DD_TB + DD_TV)) {
+        const uint64_t vw = (uint64_t)(tile_lo >> 5) + (tid - DD_TB);
+        return (vw < a.valid_words) ? a.valid[vw] : 0u;
+    }
+    return 0u;
+}
+// window at tile-relative position o: valid iff its K positions are; key = the reference's k-mer id (K <= 8)
+__device__ __forceinline__ bool dd_window(const DDTile &T, uint32_t o, int K, uint32_t &key) {
+    const uint32_t vi = o >> 5, bi = o >> 4;
+    const u64 v = ((u64)T.sv[vi + 1] << 32) | T.sv[vi];
+    const u64 x = ((u64)T.sb[bi] << 32) | T.sb[bi + 1];
+    const uint32_t need = (1u << K) - 1u;
+    key = (uint32_t)(x >> (64u - 2u * (o & 15u) - 2u * (uint32_t)K)) & ((1u << (2 * K)) - 1u);
+    return ((uint32_t)(v >> (o & 31u)) & need) == need;
+}
+
+// Calls f(integral_constant<int, n>) for the wave-uniform n in 0 .. DD_W: the per-isoform code is unrolled for exactly
+// the windows an isoform's stretch reaches in this wave, not for all six.
+template <class F>
+__device__ __forceinline__ void dd_dispatch(uint32_t n, const F &f) {
+    switch (n) {
+        case 0: break;
+        case 1: f(std::integral_constant<int, 1>{}); break;
+        case 2: f(std::integral_constant<int, 2>{}); break;
+        case 3: f(std::integral_constant<int, 3>{}); break;
+        case 4: f(std::integral_constant<int, 4>{}); break;
+        case 5: f(std::integral_constant<int, 5>{}); break;
+        default: f(std::integral_constant<int, 6>{}); break;
+    }
+}
+
+// Thread tid takes the windows at tile positions tid, tid + DD_NT, ... (DD_W of them): an isoform's stretch of the tile
+// is then spread over ALL 16 waves (a stretch of 2400 positions is two or three windows per thread), instead of keeping
+// 6 of them busy with six windows each while the others wait at the barrier.
+template <bool SCATTER>
+__global__ __launch_bounds__(DD_NT) void k_dd(DDArgs a, uint32_t *hist, uint32_t *rec_total, uint32_t *out, uint32_t colbits,
+                                              DDEscape *esc, uint32_t esc_cap, uint32_t *scal) {
+    constexpr uint32_t NSET = 8;                          // !SCATTER: 4^K-bit sets, one per isoform in flight
+    constexpr uint32_t TABW = SCATTER ? 32768u : NSET * 2048u;  // SCATTER: 4^K 16-bit count fields
+    constexpr int NRS = 255;                             // record boundaries staged at a time
+    __shared__ uint32_t tab[TABW];
+    __shared__ uint32_t sent[SCATTER ? DD_C : 1];
+    __shared__ uint32_t cnt[RADIX], lbase[RADIX + 1], gbase[RADIX];
+    __shared__ uint32_t s_rs[NRS + 1];
+    __shared__ uint32_t swave[RADIX / 64];
+    __shared__ DDTile T;
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6, w = blockIdx.x;
+    const uint32_t r_lo = a.wg_rec[w], r_hi = a.wg_rec[w + 1];
+    if (r_lo >= r_hi) return;
+    const int K = a.K;
+    const uint32_t bm_words = ((1u << (2 * K)) + 31u) / 32u;  // words of one 4^K-bit set
+    const uint32_t tab_words = SCATTER ? (1u << (2 * K)) / 2u : NSET * bm_words;
+    const uint32_t fmax = (1u << (24u - colbits)) - 1u;
+    // !SCATTER: isoform after isoform takes the next set of the ring, and NO barrier separates them (a wave goes on to the
+    // next isoform as soon as its own windows are done); sets [dirty_lo, slot) belong to finished isoforms and are
+    // cleared at the end of the tile, or when the ring is full
+    uint32_t slot = 0, dirty_lo = 0;
+    auto clear_sets = [&](uint32_t from, uint32_t n_sets) {  // all threads, between two barriers
+        for (uint32_t q = 0; q < n_sets; ++q) {
+            const uint32_t b0 = ((from + q) % NSET) * bm_words;
+            for (uint32_t i = tid; i < bm_words; i += DD_NT) tab[b0 + i] = 0;
+        }
+    };
+    for (uint32_t i = tid; i < tab_words; i += DD_NT) tab[i] = 0;
+    if (tid < RADIX) cnt[tid] = 0;
+    uint32_t r_base = r_lo;
+    auto load_rs = [&]() {  // s_rs[i] = rec_start[r_base + i]; all threads
+        lds_sync();
+        for (uint32_t i = tid; i <= (uint32_t)NRS; i += DD_NT) {
+            const uint32_t rr = r_base + i;
+            s_rs[i] = (uint32_t)a.rec_start[rr < a.n_rec ? rr : a.n_rec];
+        }
+        lds_sync();
+    };
+    load_rs();
+    uint32_t b_cur = s_rs[0], b_nxt = s_rs[1], b_nn = s_rs[2];  // rec_start of records r, r + 1, r + 2
+    const uint32_t P_lo = s_rs[0], P_hi = (uint32_t)a.rec_start[r_hi];
+    const uint32_t t_first = P_lo / DD_C, t_last = (P_hi - 1u) / DD_C;  // a record holds at least its separator
+    uint32_t r = r_lo;
+    const uint32_t wave_t0 = wv * 64u;  // the wave's first thread
+    uint32_t nxw = dd_tile_fetch(a, t_first * DD_C, tid);
+    uint32_t gb = 0, gc = 0;  // SCATTER: position of the first entry of (digit tid, this row); entries of the row
+    if (SCATTER && tid < RADIX) {
+        const uint64_t row = (uint64_t)t_first + w;
+        gb = hist[row * RADIX + tid];
+        gc = hist[(row + 1) * RADIX + tid] - gb;
+    }
+    KK_STAMP_BEGIN();
+    for (uint32_t t = t_first; t <= t_last; ++t) {
+        KK_STAMP(7);
+        const uint32_t tile_lo = t * DD_C;
+        const uint32_t tile_hi = (tile_lo + DD_C < P_hi) ? tile_lo + DD_C : P_hi;
+        // (the previous tile ended with a barrier: T is free)
+        if (tid < (uint32_t)DD_TB)
+            T.sb[tid] = nxw;
+        else if (tid < (uint32_t)(DD_TB + DD_TV))
+            T.sv[tid - DD_TB] = nxw;
+        if (t < t_last) nxw = dd_tile_fetch(a, (t + 1) * DD_C, tid);
+        uint32_t inc = 0;
+        if constexpr (SCATTER) {  // LDS slot of every digit's first entry = exclusive scan of the row's counts
+            inc = (tid < RADIX) ? gc : 0u;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t x = __shfl_up(inc, o);
+                if (lane >= (uint32_t)o) inc += x;
+            }
+            if (tid < RADIX && lane == 63) swave[wv] = inc;
+        }
+        lds_sync();
+        uint32_t key[DD_W], okm = 0;
+#pragma unroll
+        for (int j = 0; j < DD_W; ++j) okm |= (uint32_t)dd_window(T, tid + (uint32_t)j * DD_NT, K, key[j]) << j;
+        // the six 16-bit ids in three registers: the per-isoform code below walks only the windows j0 .. j0 + n - 1 that
+        // the isoform's stretch can reach in this wave (j0, n wave-uniform), and picks key j with a shift
+        // (shifts, not a select among registers: the compiler turns such a select chain into a table in scratch memory)
+        const u64 kq = (u64)(key[0] | (key[1] << 16)) | ((u64)(key[2] | (key[3] << 16)) << 32);
+        const uint32_t kr = key[4] | (key[5] << 16);
+        auto key_at = [kq, kr](uint32_t j) -> uint32_t {
+            const uint32_t lo4 = (uint32_t)(kq >> ((j & 3u) * 16u)), hi2 = kr >> ((j & 1u) * 16u);
+            return ((j < 4u) ? lo4 : hi2) & 0xFFFFu;
+        };
+        if constexpr (SCATTER) {
+            if (tid < RADIX) {
+                uint32_t before = 0;
+#pragma unroll
+                for (int i = 0; i < RADIX / 64; ++i)
+                    if ((uint32_t)i < wv) before += swave[i];
+                lbase[tid] = before + inc - gc;
+                if (tid == RADIX - 1) lbase[RADIX] = before + inc;
+                gbase[tid] = gb;
+                cnt[tid] = 0;
+                if (t < t_last) {
+                    const uint64_t row = (uint64_t)t + 1 + w;
+                    gb = hist[row * RADIX + tid];
+                    gc = hist[(row + 1) * RADIX + tid] - gb;
+                }
+            }
+            lds_sync();
+        }
+        KK_STAMP(0);  // tile start: stage + decode, digit starts
+        // ---- the isoforms that have bases in this tile, one after the other
+        while (r < r_hi) {
+            if (r + 2 - r_base > (uint32_t)NRS) {  // (uniform) the staged boundaries are used up
+                r_base = r;
+                load_rs();
+                b_cur = s_rs[0];
+                b_nxt = s_rs[1];
+                b_nn = s_rs[2];
+            }
+            // bases [ra, re), separator at re: the same for every thread, so in scalar registers.  (b_nn, the bound after
+            // the next, was read from LDS an isoform ago: no round trip here.)
+            // (kept in vector registers on purpose: the CU's one scalar unit serves all 16 waves, and a few dozen scalar
+            // instructions per wave and isoform made it the kernel's bottleneck)
+            const uint32_t ra = b_cur, re = b_nxt - 1u;
+            if (ra >= tile_hi) break;
+            const bool ends_here = re < tile_hi;
+            if (re - ra >= (uint32_t)K) {  // the isoform has windows
+                // the thread's windows inside the isoform's stretch [sl, sh) of the tile: positions tid + j * DD_NT, so
+                // j in [jlo, jhi).  (A window that runs over the isoform's end is invalid: the separator's bit is 0.)
+                const uint32_t sl = (ra > tile_lo ? ra : tile_lo) - tile_lo, sh_ = (re < tile_hi ? re : tile_hi) - tile_lo;
+                const int dlo = (int)sl - (int)tid + (DD_NT - 1), dhi = (int)sh_ - (int)tid + (DD_NT - 1);
+                const uint32_t jlo = (uint32_t)(dlo < 0 ? 0 : dlo / DD_NT), jhi = (uint32_t)(dhi < 0 ? 0 : dhi / DD_NT);  // <= DD_W
+                const uint32_t m = okm & ((1u << jhi) - 1u) & ~((1u << jlo) - 1u);
+                // the same bounds for the wave's last / first lane (jlo, jhi fall with tid): windows j0 .. j0 + nj - 1
+                const int wlo = (int)sl - (int)wave_t0 - 63 + (DD_NT - 1), whi = (int)sh_ - (int)wave_t0 + (DD_NT - 1);
+                const uint32_t j0 = (uint32_t)__builtin_amdgcn_readfirstlane(wlo < 0 ? 0 : wlo / DD_NT);
+                const uint32_t nj = (uint32_t)__builtin_amdgcn_readfirstlane(whi < 0 ? 0 : whi / DD_NT) - j0;
+                KK_STAMP(1);  // isoform bounds
+                if constexpr (!SCATTER) {
+                    const uint32_t bm0 = slot * bm_words;
+                    // all of the thread's returning atomics first, then what depends on them (one round trip)
+                    auto body = [&](auto nc) {
+                        constexpr int N = decltype(nc)::value;
+                        uint32_t old[N], kk_[N];
+#pragma unroll
+                        for (int u = 0; u < N; ++u) {
+                            const uint32_t j = j0 + (uint32_t)u;
+                            kk_[u] = key_at(j);
+                            old[u] = ~0u;
+                            if ((m >> j) & 1u)
+                                old[u] = __hip_atomic_fetch_or(&tab[bm0 + (kk_[u] >> 5)], 1u << (kk_[u] & 31u), __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        // valid windows (the reference's total_count): scalar popcounts of ballots, one global add per wave
+                        uint32_t nv = 0;
+#pragma unroll
+                        for (int u = 0; u < N; ++u) nv += (uint32_t)__popcll(__ballot((m >> (j0 + (uint32_t)u)) & 1u));
+                        if (lane == 0 && nv) atomicAdd(&rec_total[r], nv);
+#pragma unroll
+                        for (int u = 0; u < N; ++u)
+                            if (!((old[u] >> (kk_[u] & 31u)) & 1u)) atomicAdd(&cnt[kk_[u] & 255u], 1u);  // the k-mer's first occurrence
+                    };
+                    dd_dispatch(nj, body);
+                    KK_STAMP(2);  // set + histogram atomics
+                    if (ends_here) {
+                        slot = (slot + 1u) % NSET;
+                        if (slot == dirty_lo) {  // the ring is full (a tile of many short isoforms): clear all of it
+                            lds_sync();
+                            clear_sets(0, NSET);
+                            lds_sync();
+                        }
+                        KK_STAMP(5);
+                    }
+                } else {
+                    if (ra >= tile_lo) {  // the isoform starts here: count ALL its windows before any is claimed
+                        const bool check = (re - ra) >= 65535u + (uint32_t)K;  // 65536 windows or more: a field may wrap
+                        auto add = [&](const uint32_t (&kk_)[DD_W], uint32_t mm) {
+#pragma unroll
+                            for (int j = 0; j < DD_W; ++j) {
+                                if ((mm >> j) & 1u) {
+                                    const uint32_t sh = (kk_[j] & 1u) * 16u;
+                                    if (!check) {
+                                        atomicAdd(&tab[kk_[j] >> 1], 1u << sh);
+                                    } else {
+                                        const uint32_t old = atomicAdd(&tab[kk_[j] >> 1], 1u << sh);
+                                        if (((old >> sh) & 0xFFFFu) == 0xFFFFu) scal[6] = 1u;
+                                    }
+                                }
+                            }
+                        };
+                        auto add_body = [&](auto nc) {
+                            constexpr int N = decltype(nc)::value;
+#pragma unroll
+                            for (int u = 0; u < N; ++u) {
+                                const uint32_t j = j0 + (uint32_t)u;
+                                if ((m >> j) & 1u) {
+                                    const uint32_t kj = key_at(j), sh = (kj & 1u) * 16u;
+                                    if (!check) {
+                                        atomicAdd(&tab[kj >> 1], 1u << sh);
+                                    } else {
+                                        const uint32_t old = atomicAdd(&tab[kj >> 1], 1u << sh);
+                                        if (((old >> sh) & 0xFFFFu) == 0xFFFFu) scal[6] = 1u;
+                                    }
+                                }
+                            }
+                        };
+                        dd_dispatch(nj, add_body);
+                        // the rest of a long isoform: DD_W consecutive windows per thread, straight from the store
+                        for (uint32_t tt = t + 1; (uint64_t)tt * DD_C < re; ++tt) {
+                            const uint32_t g0 = tt * DD_C + DD_W * tid;
+                            if (g0 - DD_W * lane >= re) break;  // (wave-uniform) nothing of it in this wave's positions
+                            const DDWords xw = dd_fetch(a, g0);
+                            uint32_t k2[DD_W], ok2;
+                            dd_decode(xw, g0, K, k2, ok2);
+                            const int64_t eh = (int64_t)re - (int64_t)g0;
+                            const uint32_t jh = eh < 0 ? 0u : (eh > DD_W ? (uint32_t)DD_W : (uint32_t)eh);
+                            add(k2, ok2 & ((1u << jh) - 1u));
+                        }
+                        KK_STAMP(2);  // count
+                        lds_sync();
+                        KK_STAMP(3);
+                    }
+                    // claim: all returning atomics of the thread first.  Once every wave has its answers the table is
+                    // clean again, so the barrier that lets the next isoform count comes HERE; the ranks and the staging of
+                    // this isoform's entries (other LDS arrays) then run beside the next isoform's counting.
+                    uint32_t cc[DD_W], kc[DD_W];
+                    auto claim = [&](auto nc) {
+                        constexpr int N = decltype(nc)::value;
+#pragma unroll
+                        for (int u = 0; u < N; ++u) {
+                            const uint32_t j = j0 + (uint32_t)u;
+                            kc[u] = key_at(j);
+                            cc[u] = 0;
+                            if ((m >> j) & 1u) {
+                                const uint32_t sh = (kc[u] & 1u) * 16u;
+                                const uint32_t old = __hip_atomic_fetch_and(&tab[kc[u] >> 1], ~(0xFFFFu << sh), __ATOMIC_RELAXED,
+                                                                            __HIP_MEMORY_SCOPE_WORKGROUP);
+                                cc[u] = (old >> sh) & 0xFFFFu;
+                            }
+                        }
+                    };
+                    dd_dispatch(nj, claim);
+                    KK_STAMP(4);  // claim
+                    if (ends_here) lds_sync();
+                    KK_STAMP(5);
+                    const uint32_t rr = r;
+                    auto stage = [&](auto nc) {
+                        constexpr int N = decltype(nc)::value;
+                        uint32_t slot[N];
+#pragma unroll
+                        for (int u = 0; u < N; ++u) {
+                            slot[u] = 0;
+                            if (cc[u]) {  // first to claim the k-mer: this window emits its entry
+                                const uint32_t d = kc[u] & 255u;
+                                slot[u] = atomicAdd(&cnt[d], 1u) + lbase[d];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < N; ++u) {
+                            if (cc[u]) {
+                                const uint32_t f = (cc[u] - 1u < fmax) ? cc[u] - 1u : fmax;
+                                if (slot[u] < (uint32_t)DD_C) sent[slot[u]] = ((kc[u] >> 8) << 24) | (f << colbits) | rr;
+                                if (f == fmax) {  // a count the entry's field cannot hold (poly-A): queued, patched after the last pass
+                                    const uint32_t at = atomicAdd(&scal[7], 1u);
+                                    if (at < esc_cap)
+                                        esc[at] = DDEscape{kc[u], rr, cc[u]};
+                                    else
+                                        scal[6] = 1u;
+                                }
+                            }
+                        }
+                    };
+                    dd_dispatch(nj, stage);
+                    KK_STAMP(5);
+                }
+            }
+            if (!ends_here) break;
+            ++r;
+            b_cur = b_nxt;
+            b_nxt = b_nn;
+            b_nn = s_rs[(r + 2 - r_base <= (uint32_t)NRS) ? r + 2 - r_base : 0u];
+        }
+        // ---- end of the tile
+        KK_STAMP(1);
+        lds_sync();
+        if constexpr (!SCATTER) {
+            if (tid < RADIX) {
+                hist[((uint64_t)t + w) * RADIX + tid] = cnt[tid];
+                cnt[tid] = 0;
+            }
+            clear_sets(dirty_lo, (slot + NSET - dirty_lo) % NSET);  // the finished isoforms' sets (an unfinished one keeps `slot`)
+            dirty_lo = slot;
+        } else {
+            if (tid < RADIX && cnt[tid] != lbase[tid + 1] - lbase[tid]) scal[3] = 3u;  // the two kernels disagree: a bug
+            // a half-wave per digit (runs of ~24 entries, whole runs per store instruction); the bounds of the half-wave's
+            // 8 digits are read first, then all first chunks, then stored: two LDS round trips for the common case
+            constexpr int DPH = RADIX / (2 * (DD_NT / 64));  // digits per half-wave
+            const uint32_t d0 = wv * (2 * DPH) + (lane >> 5) * DPH, l5 = lane & 31u;
+            uint32_t s0[DPH], n[DPH], g0[DPH], v[DPH];
+#pragma unroll
+            for (int it = 0; it < DPH; ++it) {
+                s0[it] = lbase[d0 + it];
+                n[it] = lbase[d0 + it + 1] - s0[it];
+                g0[it] = gbase[d0 + it];
+            }
+#pragma unroll
+            for (int it = 0; it < DPH; ++it) v[it] = (l5 < n[it]) ? sent[s0[it] + l5] : 0u;
+#pragma unroll
+            for (int it = 0; it < DPH; ++it) {
+                if (l5 < n[it]) out[g0[it] + l5] = v[it];
+                for (uint32_t i = l5 + 32u; i < n[it]; i += 32u) out[g0[it] + i] = sent[s0[it] + i];
+            }
+        }
+        lds_sync();
+        KK_STAMP(6);  // flush
+    }
+    KK_STAMP_END(SCATTER ? 8 : 0);
+}
+
+// rowcount[high << 8 | low] = entries of that k-mer, from the partitioned array `ent` (regions0: the 257 region bounds
+// of the low digit) and the scanned tile histogram of the high digit (base1, one extra all-zero row at the end): whole
+// tiles inside a region are a difference of two scanned rows, the ragged ends are counted here.  One workgroup per region.
+__global__ __launch_bounds__(RADIX) void k_row_counts(const uint32_t *ent, const uint32_t *regions0, const uint32_t *base1,
+                                                      uint32_t n_hi, uint32_t *rowcount) {
+    __shared__ uint32_t h[RADIX];
+    const uint32_t lo = blockIdx.x, hi = threadIdx.x;
+    h[hi] = 0;
+    __syncthreads();
+    const uint32_t begin = regions0[lo], end = regions0[lo + 1];
+    const uint32_t ta = (begin + TILE - 1) / TILE, tb = end / TILE;  // whole tiles [ta, tb)
+    uint32_t full = 0;
+    uint32_t e0 = end, b1 = end;  // ragged ranges [begin, e0) and [b1, end)
+    if (ta < tb) {
+        full = base1[(uint64_t)tb * RADIX + hi] - base1[(uint64_t)ta * RADIX + hi];
+        e0 = ta * TILE;
+        b1 = tb * TILE;
+    }
+    for (uint32_t i = begin + hi; i < e0; i += RADIX) atomicAdd(&h[ent[i] >> 24], 1u);
+    for (uint32_t i = b1 + hi; i < end; i += RADIX) atomicAdd(&h[ent[i] >> 24], 1u);
+    __syncthreads();
+    if (hi < n_hi) rowcount[(hi << 8) | lo] = full + h[hi];
+}
+
+// row_ind[k] = exclusive prefix sum of rowcount (M <= 65536 rows, one workgroup)
+__global__ __launch_bounds__(1024) void k_row_ptr(const uint32_t *rowcount, uint32_t M, uint64_t *row_ind) {
+    __shared__ uint32_t sw[16];
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const uint32_t per = (M + 1023u) / 1024u, k0 = tid * per;
+    uint32_t s = 0;
+    for (uint32_t i = 0; i < per; ++i)
+        if (k0 + i < M) s += rowcount[k0 + i];
+    uint32_t inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t x = __shfl_up(inc, o);
+        if (lane >= (uint32_t)o) inc += x;
+    }
+    if (lane == 63) sw[wv] = inc;
+    __syncthreads();
+    uint32_t run = inc - s;
+    for (uint32_t i = 0; i < wv; ++i) run += sw[i];
+    for (uint32_t i = 0; i < per; ++i) {
+        if (k0 + i < M) {
+            row_ind[k0 + i] = run;
+            run += rowcount[k0 + i];
+        }
+    }
+    if (tid == 1023) row_ind[M] = run;
+}
+
+// The last partition pass of the small-K path: stable by the high digit (entry bits 24..31), and instead of entries it
+// writes the CSR arrays themselves -- column and value = float(count) / float(valid windows of the column), the
+// reference's `float(count) / total_count` (src/libkmers.cpp:236).  Same ranking as k_scatter.
+__global__ __launch_bounds__(NT, 4) void k_final_scatter(const uint32_t *in, const uint32_t *p_count, const uint32_t *tilebase,
+                                                         const uint32_t *rec_total, uint32_t colbits, uint64_t first_col,
+                                                         uint64_t max_nz, float *data, uint64_t *col_ind) {
+    __shared__ __attribute__((aligned(16))) uint32_t sent[TILE];
+    __shared__ uint32_t wcnt[NW][RADIX];
+    __shared__ uint32_t s_n[RADIX];     // entries of every digit in the current tile
+    __shared__ uint32_t stmp[NW];
+    // Write-out in whole 128-byte lines: the entries of digit d go to consecutive output positions across ALL the tiles
+    // of this workgroup, so the tail of a tile's run that does not fill its 32-entry group (32 floats = one line of data,
+    // two of col_ind) waits here for the next tile's entries of that digit.  Only the first and the last group of a
+    // digit in the workgroup's range are written in part.
+    __shared__ uint32_t carry[RADIX][32];
+    __shared__ uint32_t cpend[RADIX], cpos[RADIX];  // waiting entries of the digit / output position of the first of them
+    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
+    const uint32_t E = *p_count;
+    const uint32_t nt = (uint32_t)(((uint64_t)E + TILE - 1) / TILE);
+    const uint32_t per = (nt + gridDim.x - 1) / gridDim.x;
+    const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < nt) ? t0 + per : nt;
+    if (t0 >= t1) return;
+    u64 *const smask = reinterpret_cast<u64 *>(sent);
+    const uint32_t colmask = (1u << colbits) - 1u, fmask = (1u << (24u - colbits)) - 1u;
+    uint32_t e[IPT];
+    auto load_tile = [&](uint32_t t) {
+        const uint32_t c0 = t * TILE + w * WCHUNK;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint64_t i = (uint64_t)c0 + j * 64 + lane;
+            e[j] = (i < E) ? in[i] : 0u;
+        }
+    };
+    load_tile(t0);
+    if (tid < RADIX) {
+        cpend[tid] = 0;
+        cpos[tid] = tilebase[(uint64_t)t0 * RADIX + tid];
+    }
+    auto emit = [&](uint32_t pos, uint32_t v, uint32_t tot) {
+#ifdef KK_FS_NOSTORE  // diagnostic builds (wrong results): what the stores cost
+        if (tot == 0x7FFFFFFFu)
+#endif
+        if ((uint64_t)pos < max_nz) {
+            // both operands rounded to float, one IEEE division (hipcc's default float division is correctly rounded);
+            // an escaped count (f == fmask) is patched by k_fix_escapes
+            const uint32_t f = (v >> colbits) & fmask;
+            data[pos] = (float)(f + 1u) / (float)tot;
+            col_ind[pos] = first_col + (v & colmask);
+        }
+    };
+    const uint32_t hw = tid >> 5, l5 = tid & 31u;  // a half-wave per digit, 16 digits per half-wave and tile
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+        const uint64_t base = (uint64_t)tile * TILE;
+        for (uint32_t i = tid; i < NW * RADIX; i += NT) {
+            (&wcnt[0][0])[i] = 0;
+            smask[i] = 0ull;
+        }
+        lds_sync();
+        uint32_t wl = w * WCHUNK + lane;
+        asm volatile("" : "+v"(wl));
+        const uint32_t n_valid = (uint32_t)((E - base < TILE) ? E - base : TILE);
+        uint32_t *const wrow = &wcnt[w][0];
+        u64 *const wmask = &smask[w * RADIX];
+        uint32_t rank[IPT];
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const bool ok = wl + j * 64 < n_valid;
+            const uint32_t d = e[j] >> 24;
+            u64 m = 0;
+            uint32_t before = 0;
+            if (ok) {
+                atomicOr(&wmask[d], 1ull << lane);
+                m = wmask[d];
+                before = wrow[d];
+            }
+            const uint32_t m_lo = (uint32_t)m, m_hi = (uint32_t)(m >> 32);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+            rank[j] = ok ? (before + below) : NONE;
+            if (ok && below == 0) {
+                wrow[d] = before + (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);
+                wmask[d] = 0ull;
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_sync();
+        uint32_t dtot = 0;
+        uint32_t wc[NW];
+        if (tid < RADIX) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                wc[i] = dtot;
+                dtot += wcnt[i][tid];
+            }
+        }
+        uint32_t tile_count;
+        const uint32_t dstart = block_excl_scan<true>(dtot, stmp, tile_count);
+        if (tid < RADIX) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) wcnt[i][tid] = dstart + wc[i];
+            s_n[tid] = dtot;
+        }
+        lds_sync();
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            if (rank[j] != NONE) sent[wrow[e[j] >> 24] + rank[j]] = e[j];
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tile + 1 < t1) load_tile(tile + 1);
+        lds_sync();
+        // four digits per half-wave at a time: their bounds, then their entries, then the gathers of the column totals,
+        // then the stores (one group each in the common case; the loop over k takes the longer runs)
+        constexpr int DB = 4;
+#pragma unroll 1
+        for (int it = 0; it < RADIX / (NT / 32); it += DB) {
+            uint32_t ls[DB], np[DB], p[DB], ps[DB], a[DB], full[DB];
+            uint32_t maxfull = 0;
+#pragma unroll
+            for (int u = 0; u < DB; ++u) {
+                const uint32_t d = hw + (uint32_t)(it + u) * (NT / 32);
+                ls[u] = wcnt[0][d];
+                np[u] = s_n[d];
+                p[u] = cpend[d];
+                ps[u] = cpos[d];
+            }
+#pragma unroll
+            for (int u = 0; u < DB; ++u) {
+                a[u] = ps[u] & 31u;
+                full[u] = (a[u] + p[u] + np[u]) >> 5;  // complete 32-entry groups
+                maxfull = full[u] > maxfull ? full[u] : maxfull;
+            }
+            for (uint32_t k = 0; __any(k < maxfull); ++k) {
+                uint32_t v[DB], tot[DB];
+                int idx[DB];
+#pragma unroll
+                for (int u = 0; u < DB; ++u) {
+                    const uint32_t d = hw + (uint32_t)(it + u) * (NT / 32);
+                    idx[u] = (k < full[u]) ? (int)(32u * k + l5) - (int)a[u] : -1;  // < 0: before the workgroup's first entry
+                    v[u] = 0;
+                    if (idx[u] >= 0) v[u] = ((uint32_t)idx[u] < p[u]) ? carry[d][idx[u]] : sent[ls[u] + (uint32_t)idx[u] - p[u]];
+                }
+#pragma unroll
+#ifdef KK_FS_NOGATHER  // diagnostic builds (wrong results): what the gather of the column totals costs
+                for (int u = 0; u < DB; ++u) tot[u] = (v[u] & colmask) | 1u;
+#else
+                for (int u = 0; u < DB; ++u) tot[u] = (idx[u] >= 0) ? rec_total[v[u] & colmask] : 1u;
+#endif
+#pragma unroll
+                for (int u = 0; u < DB; ++u)
+                    if (idx[u] >= 0) emit(ps[u] + (uint32_t)idx[u], v[u], tot[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < DB; ++u) {  // what stays for the next tile
+                const uint32_t d = hw + (uint32_t)(it + u) * (NT / 32);
+                const uint32_t rs = full[u] ? 32u * full[u] - a[u] : 0u, rem = p[u] + np[u] - rs;
+                // (with a complete group, everything that stays is new: the waiting entries never reach past their group)
+                if (l5 < rem && (full[u] || l5 >= p[u])) carry[d][l5] = sent[ls[u] + rs + l5 - p[u]];
+                if (l5 == 0) {
+                    cpend[d] = rem;
+                    cpos[d] = ps[u] + rs;
+                }
+            }
+        }
+        lds_sync();
+    }
+    // the last, incomplete group of every digit
+#pragma unroll 1
+    for (int it = 0; it < RADIX / (NT / 32); ++it) {
+        const uint32_t d = hw + (uint32_t)it * (NT / 32);
+        const uint32_t p = cpend[d], ps = cpos[d];
+        if (l5 < p) {
+            const uint32_t v = carry[d][l5];
+            emit(ps + l5, v, rec_total[v & colmask]);
+        }
+    }
+}
+
+// Entries whose count did not fit the count field: find the (row, column) in the finished CSR and write the value.
+__global__ void k_fix_escapes(const DDEscape *esc, const uint32_t *scal, uint32_t esc_cap, const uint64_t *row_ind,
+                              const uint64_t *col_ind, const uint32_t *rec_total, uint64_t first_col, uint64_t max_nz, float *data) {
+    uint32_t n = scal[7];
+    if (n > esc_cap) n = esc_cap;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DDEscape x = esc[i];
+    uint64_t lo = row_ind[x.key], hi = row_ind[x.key + 1];
+    if (hi > max_nz) hi = max_nz;
+    const uint64_t want = first_col + x.col;
+    while (lo < hi) {  // first entry of the row with column >= want
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (col_ind[mid] < want)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    if (lo < max_nz && col_ind[lo] == want) data[lo] = (float)x.count / (float)rec_total[x.col];
+}
+
+// ------------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------------
 
@@ -1623,19 +2330,24 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 
 struct XLayout {
     uint32_t n_tiles;
-    uint64_t hist_len;       // RADIX * n_tiles
+    uint32_t dd_rows;        // histogram rows of the small-K path: its tiles + one per workgroup + the all-zero last row
+    uint64_t hist_len;       // RADIX * (rows of the larger of the two paths)
     uint32_t scan_blocks;
     uint32_t task_cap;
+    uint32_t esc_cap;
     size_t off_entA, off_entB, off_hist, off_blocksums, off_total, off_flags, off_tilecb, off_status, off_scalars, off_regions,
-        off_tasks, bytes;
+        off_tasks, off_wgrec, off_esc, off_rowcount, bytes;
 };
 
 static XLayout x_layout(uint64_t n_pos, uint64_t n_rec, int K) {
     XLayout l;
     const uint64_t emax = n_pos ? n_pos : 1;
     l.n_tiles = (uint32_t)((emax + TILE - 1) / TILE);
-    l.hist_len = (uint64_t)RADIX * l.n_tiles;
-    l.scan_blocks = cscan_chunks(l.n_tiles);
+    l.dd_rows = (uint32_t)((emax + DD_C - 1) / DD_C) + DD_GRID + 2;
+    const uint32_t rows = (l.n_tiles + 1 > l.dd_rows) ? l.n_tiles + 1 : l.dd_rows;
+    l.hist_len = (uint64_t)RADIX * rows;
+    l.scan_blocks = cscan_chunks(rows);
+    l.esc_cap = (uint32_t)(emax < (1u << 22) ? emax : (1u << 22));
     const uint64_t M = 1ull << (2 * K);
     // long gaps: each holds > FILL_INLINE rows and follows a row head, plus the splits of very long ones
     uint64_t cap = (M + 1) / (FILL_INLINE + 1) + 2;
@@ -1659,6 +2371,9 @@ static XLayout x_layout(uint64_t n_pos, uint64_t n_rec, int K) {
     l.off_scalars = take(64);
     l.off_regions = take(2 * (RADIX + 1) * 4);
     l.off_tasks = take((size_t)l.task_cap * sizeof(FillTask));
+    l.off_wgrec = take((DD_GRID + 1) * 4);
+    l.off_esc = take((size_t)l.esc_cap * sizeof(DDEscape));
+    l.off_rowcount = take((size_t)65536 * 4);
     l.bytes = o;
     return l;
 }
@@ -1904,6 +2619,70 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     return 0;
 }
 
+// The small-K path (see "X for 5 <= K <= 8" above).  Returns 1 when the build has to be redone on the general path
+// (a 16-bit count field wrapped, or more escapes than the queue holds), else 0 / an error code.
+static int build_x_tables(const XLayout &l, const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words,
+                          const uint64_t *d_rec_start, uint64_t n_pos, uint64_t n_rec, uint64_t first_col, int K, float *d_data,
+                          uint64_t *d_col_ind, uint64_t *d_row_ind, uint64_t max_nz, char *ws, uint64_t *nnz_out, hipStream_t s,
+                          PhaseTimer &pt) {
+    const uint64_t M = 1ull << (2 * K);
+    uint32_t *entA = (uint32_t *)(ws + l.off_entA);
+    uint32_t *hist = (uint32_t *)(ws + l.off_hist), *bsum = (uint32_t *)(ws + l.off_blocksums);
+    uint32_t *total = (uint32_t *)(ws + l.off_total);
+    uint32_t *scal = (uint32_t *)(ws + l.off_scalars);  // [0]=nnz [3]=err [4]=dummy [6]=redo [7]=escapes
+    uint32_t *regs0 = (uint32_t *)(ws + l.off_regions);
+    uint32_t *wgrec = (uint32_t *)(ws + l.off_wgrec);
+    DDEscape *esc = (DDEscape *)(ws + l.off_esc);
+    uint32_t *rowcount = (uint32_t *)(ws + l.off_rowcount);
+    uint32_t colbits = 1;
+    while ((1ull << colbits) < n_rec) ++colbits;  // columns 0 .. n_rec - 1 (n_rec <= 2^22: at least 2 bits of count)
+    DDArgs a{d_bases, d_valid, bases_words, valid_words, d_rec_start, (uint32_t)n_rec, K, wgrec};
+    const uint32_t rows = l.dd_rows;  // the last one stays zero: row r's counts = scanned row r + 1 - scanned row r
+    hipLaunchKernelGGL(k_dd_ranges, dim3((DD_GRID + 1 + 255) / 256), dim3(256), 0, s, d_rec_start, (uint32_t)n_rec, n_pos,
+                       (uint32_t)DD_GRID, wgrec);
+    KK_CHECK(hipMemsetAsync(hist, 0, (size_t)rows * RADIX * 4, s));
+    pt.mark("setup");
+    hipLaunchKernelGGL(k_dd<false>, dim3(DD_GRID), dim3(DD_NT), 0, s, a, hist, total, (uint32_t *)nullptr, colbits,
+                       (DDEscape *)nullptr, 0u, scal);
+    pt.mark("k_dd<hist>");
+    if (int rc = scan_tilehist(hist, rows, bsum, &scal[0], s)) return rc;
+    pt.mark("k_scan");
+    hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, (const uint32_t *)hist, rows, (const uint32_t *)&scal[0], regs0);
+    hipLaunchKernelGGL(k_dd<true>, dim3(DD_GRID), dim3(DD_NT), 0, s, a, hist, total, entA, colbits, esc, l.esc_cap, scal);
+    pt.mark("k_dd<scatter>");
+    const uint32_t nt1 = l.n_tiles + 1;  // one tile beyond the entries: an all-zero last row for k_row_counts
+    hipLaunchKernelGGL(k_hist_entries<uint32_t>, dim3(nt1 < 2048u ? nt1 : 2048u), dim3(NT), 0, s, (const uint32_t *)entA,
+                       (const uint32_t *)&scal[0], 8, hist, nt1);
+    pt.mark("k_hist_entries");
+    if (int rc = scan_tilehist(hist, nt1, bsum, &scal[4], s)) return rc;
+    pt.mark("k_scan");
+    hipLaunchKernelGGL(k_row_counts, dim3(RADIX), dim3(RADIX), 0, s, (const uint32_t *)entA, (const uint32_t *)regs0,
+                       (const uint32_t *)hist, (uint32_t)(M >> 8), rowcount);
+    hipLaunchKernelGGL(k_row_ptr, dim3(1), dim3(1024), 0, s, (const uint32_t *)rowcount, (uint32_t)M, d_row_ind);
+    pt.mark("k_row_ptr");
+    const uint32_t pg = l.n_tiles < (uint32_t)PERSIST_BLOCKS ? l.n_tiles : (uint32_t)PERSIST_BLOCKS;
+    hipLaunchKernelGGL(k_final_scatter, dim3(pg), dim3(NT), 0, s, (const uint32_t *)entA, (const uint32_t *)&scal[0],
+                       (const uint32_t *)hist, (const uint32_t *)total, colbits, first_col, max_nz, d_data, d_col_ind);
+    pt.mark("k_final_scatter");
+    hipLaunchKernelGGL(k_fix_escapes, dim3((l.esc_cap + 255) / 256), dim3(256), 0, s, (const DDEscape *)esc, (const uint32_t *)scal,
+                       l.esc_cap, (const uint64_t *)d_row_ind, (const uint64_t *)d_col_ind, (const uint32_t *)total, first_col,
+                       max_nz, d_data);
+    pt.mark("k_fix_escapes");
+    KK_CHECK(hipGetLastError());
+    uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    KK_CHECK(hipMemcpyAsync(h, scal, sizeof h, hipMemcpyDeviceToHost, s));
+    KK_CHECK(hipStreamSynchronize(s));
+    pt.finish();
+    if (h[3]) {
+        fprintf(stderr, "libkmers: internal error %u in the small-K X build (3: the two table kernels disagree)\n", h[3]);
+        return -11;
+    }
+    if (h[6]) return 1;  // redo on the general path
+    *nnz_out = h[0];
+    if ((uint64_t)h[0] > max_nz) return -2;
+    return 0;
+}
+
 int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words, const uint64_t *d_rec_start,
             uint64_t n_pos, uint64_t n_rec, uint64_t first_col, int K, float *d_data, uint64_t *d_col_ind, uint64_t *d_row_ind,
             uint64_t max_nz, void *d_ws, size_t ws_bytes, uint64_t *nnz_out, hipStream_t s) {
@@ -1927,8 +2706,25 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         *nnz_out = 0;
         return 0;
     }
-    const size_t flag_words = (size_t)((n_pos + 31) / 32 + 4);
     KK_CHECK(hipMemsetAsync(total, 0, n_rec * 4, s));
+
+    // 5 <= K <= 8: the per-isoform LDS tables are selected with KMERS_X_PATH=tables.  Measured on config 2 they are not
+    // yet the faster of the two paths (6.0 ms against 5.6 ms: DESIGN.md section 4), so the partition path stays the default.
+    {
+        const char *e = getenv("KMERS_X_PATH");
+        const bool want_tables = e && !strcmp(e, "tables") && !getenv("KMERS_FORCE_WIDE");
+        const bool fits = K >= 5 && K <= 8 && n_rec <= DD_MAX_REC;
+        if (fits && want_tables) {
+            const int rc = build_x_tables(l, d_bases, bases_words, d_valid, valid_words, d_rec_start, n_pos, n_rec, first_col, K,
+                                          d_data, d_col_ind, d_row_ind, max_nz, ws, nnz_out, s, pt);
+            if (rc != 1) return rc;
+            pt.on = false;  // (its timeline was closed by the attempt above)
+            if (getenv("KMERS_VERBOSE")) fprintf(stderr, "libkmers: a k-mer count left the table's range: X is rebuilt on the general path\n");
+            KK_CHECK(hipMemsetAsync(scal, 0, 64, s));
+            KK_CHECK(hipMemsetAsync(total, 0, n_rec * 4, s));
+        }
+    }
+    const size_t flag_words = (size_t)((n_pos + 31) / 32 + 4);
     KK_CHECK(hipMemsetAsync(flags, 0, flag_words * 4, s));
     KK_CHECK(hipMemsetAsync(status, 0, ((size_t)l.n_tiles + 1) * 8, s));
     hipLaunchKernelGGL(k_mark_records, dim3((uint32_t)((n_rec + 255) / 256)), dim3(256), 0, s, d_rec_start, n_rec, flags);
