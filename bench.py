@@ -1,25 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the k-mer hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload x8|x14|x12|y12|y8|y14|g8|g14]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload x8|x14|y12|y14|y8|g8|g14 ...] [--only]
 
 A step = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
-  x8  (default) BASELINE.json configs[1]: synthetic GRCh38-RefSeq-shaped transcriptome, ~170k isoforms / ~400 Mbases,
-      K=8 -> CSR X (kmers_hip_build_x: shred, stable radix partition, run-length reduce, emit)
-  x14 configs[2]: the same transcriptome at K=14
-  y12 configs[3] per-GPU share: simulated 100 bp reads -> dense int32 histogram at K=12 (kmers_hip_count_y)
-  g8, g14 (not a BASELINE.json config): one logp_grad evaluation (X.theta, the log-likelihood
-      term and X^T.(y / X.theta)) on the X and y of the configs above, resident in HBM; unit non-zeros/s; for N > 1 every
-      rank holds its own isoforms as a column shard of X, y and X.theta are all-reduced (kmers_amd.distributed.ShardedModel)
-For N > 1 (one process per GPU, torchrun) every rank works on its own shard of the same shape (weak scaling: X column
-shards need no collective; y shards are summed with one RCCL all-reduce inside the timed step).
+  x8   BASELINE.json configs[1], the headline line: synthetic GRCh38-RefSeq-shaped transcriptome (seed 20240521), ~170k
+       isoforms / ~400 Mbases, K=8 -> CSR X (kmers_hip_build_x)
+  x14  configs[2]: the same transcriptome at K=14
+  y12  configs[3]: 10^8 simulated 100 bp reads (kmers_amd.simulate_reads: the reference's sampling, reads written straight
+       into HBM) -> dense int32 histogram at K=12 (kmers_hip_count_y); y14: the same reads at K=14
+  g8, g14 (not a BASELINE.json config): one logp_grad evaluation on the resident X and y
+With no --workload the line is x8 and carries an `also` list with x14, y12 and y14 timed in the same process, each with
+its own ms_per_step, roofline and cpu_baseline (--only: the headline alone).
+
+N > 1 (one process per GPU, torchrun): STRONG scaling of the same job.  The ONE transcriptome is split into N contiguous
+record ranges (kmers_store_ingest's shard arguments) and rank r builds the CSR of its columns; the ONE set of reads is
+split the same way and the histograms are summed with one RCCL all-reduce inside the timed step.  X needs no data-path
+collective; what north_star calls "concatenated on the host" is timed once, apart, after the steps (`concat`: every rank
+copies its shard over its own PCIe link and places it in a shared host buffer, kmers_amd.distributed.concat_x_shards)
+and never enters `value`, which is HBM-resident throughput as the bench contract asks.
 Rank 0 prints ONE JSON line.  `value` is k-mers/s over all ranks, a k-mer being one window position
 (sum over records of max(len-K+1, 0)).
 """
 import argparse
-import ctypes as C
+import hashlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -30,51 +37,205 @@ sys.path.insert(0, ROOT)
 
 METRIC = "k-mers/sec (transcriptome_to_x + reads->y) at K=8/14; achieved HBM GB/s"
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALSO = ["x14", "y12", "y14"]
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="x8", help="x<K>, y<K> or g<K>, K in 1..16 (x8, x14, y12 are BASELINE.json's)")
+    ap.add_argument("--workload", default=None, help="x<K>, y<K> or g<K>, K in 1..16; default x8 with x14, y12, y14 in `also`")
+    ap.add_argument("--only", action="store_true", help="no `also` list")
     ap.add_argument("--records", type=int, default=170_000)
     ap.add_argument("--bases", type=int, default=400_000_000)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU for the y workloads")
+    ap.add_argument("--reads", type=int, default=100_000_000, help="simulated reads of the y workloads, over ALL ranks")
+    ap.add_argument("--model-reads", type=int, default=10_000_000, help="reads of the g workloads (per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-concat", action="store_true", help="N > 1: skip the host concatenation of the X shards")
     ap.add_argument("--cache", default=os.environ.get("KMERS_BENCH_CACHE", "/tmp/kmers_bench"))
-    args = ap.parse_args()
-    import re
+    args = ap.parse_args(argv)
+    args.explicit = args.workload is not None
+    if args.workload is None:
+        args.workload = "x8"
     if not re.fullmatch(r"[xyg]([1-9]|1[0-6])", args.workload):
         ap.error("--workload must be x<K>, y<K> or g<K> with K in 1..16")
     return args
 
 
-def make_inputs(args, rank, want_reads):
-    """Synthetic FASTA files for this rank (cached on local disk; generation is not timed)."""
+# ------------------------------------------------------------------------------------------------ inputs (not timed)
+
+def transcriptome_file(args, seed=20240521, with_reads=0, reads_seed=42):
+    """The synthetic transcriptome FASTA (cached on local disk) and, if asked, a reads FASTA drawn from it."""
     from kmers_amd import synth
     os.makedirs(args.cache, exist_ok=True)
-    seed = 20240521 + rank
     iso = os.path.join(args.cache, f"tx_s{seed}_r{args.records}_b{args.bases}.fsa")
-    reads = os.path.join(args.cache, f"reads_s{42 + rank}_n{args.reads}_tx{seed}_r{args.records}_b{args.bases}.fsa")
-    need_reads = want_reads and not os.path.exists(reads)
+    reads = os.path.join(args.cache, f"reads_s{reads_seed}_n{with_reads}_tx{seed}_r{args.records}_b{args.bases}.fsa")
+    need_reads = with_reads and not os.path.exists(reads)
     if not os.path.exists(iso) or need_reads:
         tmp = f"{iso}.tmp{os.getpid()}"
         info = synth.synth_transcriptome(tmp, n_records=args.records, total_bases=args.bases, seed=seed,
-                                         return_sequences=need_reads)
+                                         return_sequences=bool(need_reads))
         os.replace(tmp, iso)
         if need_reads:
             tmp = f"{reads}.tmp{os.getpid()}"
-            synth.synth_reads(tmp, info["concat"], info["offsets"], args.reads, read_len=100, seed=42 + rank)
+            synth.synth_reads(tmp, info["concat"], info["offsets"], with_reads, read_len=100, seed=reads_seed)
             os.replace(tmp, reads)
-    return iso, reads
+    return iso, (reads if with_reads else None)
+
+
+def make_inputs(args, rank, want_reads):
+    """(transcriptome FASTA, reads FASTA) of the g workloads and the tools: a transcriptome of this rank's own."""
+    return transcriptome_file(args, seed=20240521 + rank, with_reads=args.model_reads if want_reads else 0,
+                              reads_seed=42 + rank)
+
+
+class Ctx:
+    """Process-wide state of one bench run."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.args, self.torch, self.dist = args, torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        # KMERS_BENCH_REHEARSAL=1: several ranks on ONE GPU over gloo (RCCL refuses two ranks on a device) -- to rehearse
+        # the multi-rank control flow on a one-GPU box; never a measurement
+        self.rehearsal = os.environ.get("KMERS_BENCH_REHEARSAL") == "1"
+        if self.rehearsal:
+            local = 0
+        torch.cuda.set_device(local)
+        self.dev = torch.device("cuda", local)
+        if self.world > 1:
+            if self.rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)
+        self._iso = None
+        self._xstore = None
+        self._reads = None
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def all_max_sum(self, t_local, *sums):
+        """max over ranks of t_local, sums over ranks of the rest."""
+        torch, dist = self.torch, self.dist
+        if self.world == 1:
+            return (t_local,) + tuple(float(s) for s in sums)
+        dev = torch.device("cpu") if self.rehearsal else self.dev
+        tm = torch.tensor([t_local], dtype=torch.float64, device=dev)
+        sm = torch.tensor([float(s) for s in sums] or [0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        return (float(tm[0].item()),) + tuple(float(v) for v in sm[:len(sums)].tolist())
+
+    def all_reduce_dev(self, t):
+        """sum of a device tensor over the ranks (RCCL over xGMI; through the host in a gloo rehearsal)."""
+        if self.world == 1:
+            return
+        if self.rehearsal:
+            h = t.cpu()
+            self.dist.all_reduce(h)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t)
+
+    def iso_file(self):
+        if self._iso is None:
+            if self.rank == 0:
+                self._iso = transcriptome_file(self.args)[0]
+            if self.world > 1:
+                self.dist.barrier()          # one node: the other ranks read rank 0's file
+            self._iso = transcriptome_file(self.args)[0]
+        return self._iso
+
+    def x_store(self):
+        """This rank's shard (contiguous record range) of the ONE transcriptome, host and device side."""
+        if self._xstore is None:
+            from kmers_amd.store import MODE_X, Store
+            st = Store(self.iso_file(), MODE_X, shard=self.rank, n_shards=self.world)
+            self._xstore = (st, st.to_device(self.dev))
+        return self._xstore
+
+    def reads_store(self):
+        """This rank's share of the ONE set of simulated reads, in HBM (kmers_hip_simulate_reads)."""
+        if self._reads is None:
+            from kmers_amd.simulate_reads import simulate_reads_device
+            ds, _ = simulate_reads_device(self.args.reads, 100, 0.1, self.iso_file(), device=self.dev, shard=self.rank,
+                                          n_shards=self.world)
+            self._reads = ds
+        return self._reads
+
+
+# ------------------------------------------------------------------------------------------------ measurement helpers
+
+def kernels_sha():
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "model.hip"):
+        with open(os.path.join(ROOT, "kmers_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(workload, kernel, default_size):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of this same command (tools/pmc.sh +
+    tools/pmc_traffic.py write profiles/pmc_traffic.json; counters cannot be read from inside the process).  Only quoted
+    when the file was made from the kernel sources that are in the tree now and for the default sizes."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not default_size or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        allw = json.load(f)
+    w = allw.get(workload, {})
+    if w.get("kernels_sha") != kernels_sha():
+        return None
+    return w.get("kernels", {}).get(kernel, {}).get("bytes")
+
+
+def timed(ctx, step):
+    """W warm-up steps, then exactly K steps between two fences; per-kernel HIP-event timings of the K steps."""
+    from kmers_amd import _lib
+    a = ctx.args
+    for _ in range(a.warmup):
+        step()
+    ctx.fence()
+    _lib.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    ctx.fence()
+    dt = time.perf_counter() - t0
+    table = _lib.profile_table()
+    _lib.profile(False)
+    return dt, table
+
+
+def roofline(table, kernel_bytes, path_bytes, ms_per_step, steps, workload, default_size):
+    dom = max((r for r in table if r[0] in kernel_bytes), key=lambda r: r[1], default=None)
+    if dom is None:
+        ach = path_bytes / (ms_per_step * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "whole step", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(ms_per_step, 4),
+                "algorithmic_bytes": int(path_bytes)}
+    avg_ms = dom[1] / dom[2]
+    ach = kernel_bytes[dom[0]] / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(workload, dom[0], default_size),
+            "avg_ms": round(avg_ms, 4), "launches_per_step": dom[2] // max(steps, 1),
+            "algorithmic_bytes": int(kernel_bytes[dom[0]])}
 
 
 def cpu_baseline(args, K, kind_x):
-    """The reference library itself (oracle/_ref, built in the build container from /root/reference/src) -- or, when
-    that build is absent, the oracle port -- timed on the host cores on a bounded sample of the same workload."""
-    from kmers_amd import synth
+    """The reference library itself (oracle/_ref, built in the build container from /root/reference/src) -- or, when that
+    build is absent, the oracle port -- timed on the host cores: X on the FULL transcriptome file of the GPU run, y on a
+    bounded sample of reads drawn from it the same way."""
     from tests import kmtest
+    from kmers_amd.store import MODE_X, MODE_Y_FASTA, Store
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libkmers_ref.so")
     cores = min(16, os.cpu_count() or 1)
     os.environ["KMER_NUM_THREADS"] = str(cores)
@@ -82,28 +243,13 @@ def cpu_baseline(args, K, kind_x):
         lib, kind = kmtest.Lib(ref_so, "", hip=False), "reference"
     else:
         lib, kind, cores = kmtest.load_oracle(), "port", 1
-    frac = 4 if kind_x else 10          # ~20-40 core-seconds of the reference either way
-    n_rec, n_bases = max(100, args.records // frac), max(100_000, args.bases // frac)
-    sample = os.path.join(args.cache, f"cpu_sample_r{n_rec}_b{n_bases}.fsa")
-    info = None
-    if not os.path.exists(sample):
-        info = synth.synth_transcriptome(sample + ".tmp", n_records=n_rec, total_bases=n_bases, seed=20240521,
-                                         return_sequences=not kind_x)
-        os.replace(sample + ".tmp", sample)
-    path = sample
-    what = f"{n_rec} isoforms / {n_bases / 1e6:.0f} Mbases of the same synthetic transcriptome"
-    if not kind_x:
-        path = sample + ".reads"
-        n_reads = max(1000, args.reads // 10)
-        if not os.path.exists(path):
-            if info is None or "concat" not in info:
-                info = synth.synth_transcriptome(sample + ".tmp", n_records=n_rec, total_bases=n_bases, seed=20240521,
-                                                 return_sequences=True)
-                os.replace(sample + ".tmp", sample)
-            synth.synth_reads(path + ".tmp", info["concat"], info["offsets"], n_reads, read_len=100, seed=42)
-            os.replace(path + ".tmp", path)
-        what = f"{n_reads} simulated 100 bp reads"
-    from kmers_amd.store import MODE_X, MODE_Y_FASTA, Store
+    if kind_x:
+        path = transcriptome_file(args)[0]
+        what = f"the full transcriptome of the GPU run ({args.records} isoforms / {args.bases / 1e6:.0f} Mbases)"
+    else:
+        n_reads = max(1000, min(2_000_000, args.reads // 50))
+        path = transcriptome_file(args, with_reads=n_reads)[1]
+        what = f"{n_reads} reads of 100 bp drawn from the same transcriptome"
     st = Store(path, MODE_X if kind_x else MODE_Y_FASTA)
     windows = st.n_windows(K)
     st.close()
@@ -113,10 +259,7 @@ def cpu_baseline(args, K, kind_x):
     os.dup2(devnull, 1)                  # the reference prints phase timings to stdout
     try:
         t0 = time.perf_counter()
-        if kind_x:
-            rc = lib.x([path], K)[0]
-        else:
-            rc = lib.y([path], K)[0]
+        rc = (lib.x([path], K) if kind_x else lib.y([path], K))[0]
         dt = time.perf_counter() - t0
     finally:
         os.dup2(saved, 1)
@@ -128,11 +271,144 @@ def cpu_baseline(args, K, kind_x):
                       f"{dt:.1f} s wall, file in page cache"}
 
 
-def bench_model(args, K, dev, rank, world, fence):
+# ------------------------------------------------------------------------------------------------ the workloads
+
+def run_x(ctx, K, tag):
+    """transcriptome_to_x's device stage on this rank's columns of the one transcriptome."""
+    args = ctx.args
+    st, ds = ctx.x_store()
+    windows, n_bases, n_rec, n_pos = st.n_windows(K), st.n_bases, st.n_rec, st.n_pos
+    M = 4 ** K
+    instances = int(ds.count_y(K).sum().item())      # valid windows (entries the X path sorts); not timed
+    buf = ds.x_buffers(K, windows)
+    nnz = 0
+
+    def step():
+        nonlocal nnz
+        nnz = ds.build_x(buf)
+
+    dt, table = timed(ctx, step)
+    concat = None
+    if ctx.world > 1 and not args.no_concat:        # what north_star calls "X columns are concatenated on the host"
+        from kmers_amd.distributed import concat_x_shards
+        ctx.fence()
+        t0 = time.perf_counter()
+        whole = concat_x_shards(buf["data"], buf["col_ind"], buf["row_ind"], nnz, M, gloo=ctx.rehearsal)
+        ctx.fence()
+        concat = time.perf_counter() - t0
+        if ctx.rank == 0:
+            assert int(whole[1][-1]) == whole[0].shape[0]
+        del whole
+    dt_max, windows_all, nnz_all, bases_all, rec_all = ctx.all_max_sum(dt, windows, nnz, n_bases, n_rec)
+    concat_max = ctx.all_max_sum(concat or 0.0)[0]
+    del buf
+    ctx.torch.cuda.empty_cache()
+    if ctx.rank != 0:
+        return None
+    ms = dt_max / args.steps * 1e3
+    E = instances
+    path_bytes = n_bases / 4 + n_bases / 8 + 8 * (n_rec + 1) + nnz * 12 + 8 * (M + 1)       # this rank (SURVEY.md 8d)
+    es = 4 if (K <= 8 and n_rec <= 1 << 24) else 8      # bytes per partition entry
+    kernel_bytes = {    # what each kernel has to move at minimum for its own job (per launch)
+        "k_hist_bases": n_pos * 3 / 8 + 8 * (n_rec + 1),
+        "k_scatter<bases>": n_pos * 3 / 8 + 8 * (n_rec + 1) + es * E,
+        "k_hist_entries": es * E,
+        "k_scatter<entries>": 2 * es * E,
+        "k_rle": es * E + 12 * nnz + 8 * (M + 1),
+        # the small-K table path (KMERS_X_PATH=tables): entries are the nnz distinct (k-mer, isoform) pairs
+        "k_dd<hist>": n_pos * 3 / 8 + 8 * (n_rec + 1),
+        "k_dd<scatter>": n_pos * 3 / 8 + 8 * (n_rec + 1) + 4 * nnz,
+        "k_final_scatter": 4 * nnz + 12 * nnz + 4 * n_rec,
+    }
+    if "k_dd<hist>" in {r[0] for r in table}:
+        kernel_bytes["k_hist_entries"] = 4 * nnz
+    default_size = (args.records, args.bases) == (170_000, 400_000_000) and ctx.world == 1
+    gbs = path_bytes / (ms * 1e-3) / 1e9
+    out = {
+        "metric": METRIC, "value": windows_all * args.steps / dt_max, "unit": "k-mers/s", "n_gpus": ctx.world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "strong" if ctx.world > 1 else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"transcriptome_to_x K={K}: {int(rec_all)} records / {bases_all / 1e6:.0f} Mbases "
+                               f"({'BASELINE.json configs[1]' if tag == 'x8' else 'configs[2]' if tag == 'x14' else tag}"
+                               + (f"; the one transcriptome in {ctx.world} column shards, one per GPU)" if ctx.world > 1 else ")"),
+                   "K": K, "records": int(rec_all), "bases": int(bases_all), "kmers": int(windows_all),
+                   "nnz": int(nnz_all), "rank0": {"records": n_rec, "bases": n_bases, "valid_instances": E, "nnz": nnz},
+                   "parallelism": f"column-shards{ctx.world}"},
+        "roofline": roofline(table, kernel_bytes, path_bytes, ms, args.steps, tag, default_size),
+        "path": {"algorithmic_bytes": int(path_bytes), "bytes_per_kmer": round(path_bytes / max(windows, 1), 3),
+                 "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)},
+        "kernels_ms": {r[0]: round(r[1] / args.steps, 4) for r in table},
+    }
+    if concat is not None:
+        out["concat"] = {"ms": round(concat_max * 1e3, 2),
+                         "what": "D2H of every rank's CSR shard over its own link + placement in one shared host CSR "
+                                 "(kmers_amd.distributed.concat_x_shards), once, outside `value`",
+                         "kmers_per_s_with_concat": windows_all / (dt_max / args.steps + concat_max)}
+    return out
+
+
+def run_y(ctx, K, tag):
+    """reads -> y on this rank's share of the one set of simulated reads; N > 1: + one all-reduce of the histogram."""
+    args, torch = ctx.args, ctx.torch
+    ds = ctx.reads_store()
+    n_reads = ds.n_rec
+    n_pos = ds.n_pos
+    windows = n_reads * max(100 - K + 1, 0)
+    M = 4 ** K
+    counts = torch.zeros(M, dtype=torch.int32, device=ctx.dev)
+    y_ws = ds.y_workspace(K)             # K >= 9: partition scratch, kept across steps
+
+    def step():
+        counts.zero_()
+        ds.count_y(K, counts, workspace=y_ws)
+        ctx.all_reduce_dev(counts)       # RCCL ring over xGMI: the reference's shared-array "+=" across GPUs
+
+    dt, table = timed(ctx, step)
+    E = int(counts.sum(dtype=torch.int64).item())      # valid windows of ALL reads (the histogram is all-reduced)
+    dt_max, windows_all, reads_all = ctx.all_max_sum(dt, windows, n_reads)
+    del y_ws
+    torch.cuda.empty_cache()
+    if ctx.rank != 0:
+        return None
+    E = E / ctx.world                                  # per rank, for the per-launch byte counts
+    ms = dt_max / args.steps * 1e3
+    n_bases = n_reads * 100
+    path_bytes = n_bases / 4 + n_bases / 8 + 4 * M
+    kernel_bytes = {
+        "k_count_y_lds": n_pos * 3 / 8 * (2 if K == 8 else 1) + 4 * M,
+        "k_count_y_global": n_pos * 3 / 8 + 8 * E,
+        "k_hist_words_y": n_pos * 3 / 8,
+        "k_scatter<bases,y>": n_pos * 3 / 8 + (2 if K <= 12 else 4) * E,   # 2-byte payloads with one pass
+        "k_hist_entries": 4 * E,
+        "k_scatter<entries>": 8 * E,
+        "k_count_y_sorted": (2 if K <= 12 else 4) * E + 8 * M,
+    }
+    n_chunks = max(1, -(-n_pos // (1 << 31)))
+    # chunked stores launch every kernel once per chunk: bytes per launch
+    kernel_bytes = {k: v / n_chunks for k, v in kernel_bytes.items()}
+    default_size = (args.records, args.bases, args.reads) == (170_000, 400_000_000, 100_000_000) and ctx.world == 1
+    gbs = path_bytes / (ms * 1e-3) / 1e9
+    return {
+        "metric": METRIC, "value": windows_all * args.steps / dt_max, "unit": "k-mers/s", "n_gpus": ctx.world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "strong" if ctx.world > 1 else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"reads->y K={K}: {int(reads_all)} simulated 100 bp reads "
+                               f"({'BASELINE.json configs[3]' if tag == 'y12' else tag}"
+                               + (f"; {ctx.world} shards, histogram all-reduced over RCCL)" if ctx.world > 1 else ")"),
+                   "K": K, "reads": int(reads_all), "kmers": int(windows_all), "reads_rank0": n_reads,
+                   "chunks_per_step": n_chunks, "parallelism": f"read-shards{ctx.world}"},
+        "roofline": roofline(table, kernel_bytes, path_bytes, ms, args.steps, tag, default_size),
+        "path": {"algorithmic_bytes": int(path_bytes), "bytes_per_kmer": round(path_bytes / max(windows, 1), 3),
+                 "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)},
+        "kernels_ms": {r[0]: round(r[1] / args.steps, 4) for r in table},
+    }
+
+
+def run_model(ctx, K):
     """g<K>: logp_grad on the resident X and y (kmers_hip_model_*).  N > 1: weak scaling over column shards -- every
     rank's transcriptome is its shard of the columns, the histogram and X.theta are all-reduced."""
-    import torch
-    from kmers_amd import _lib
+    args, torch, dist = ctx.args, ctx.torch, ctx.dist
+    rank, world, dev = ctx.rank, ctx.world, ctx.dev
     from kmers_amd.model import DeviceModel
     from kmers_amd.store import MODE_X, MODE_Y_FASTA, Store
     iso, reads = make_inputs(args, rank, want_reads=True)
@@ -143,9 +419,7 @@ def bench_model(args, K, dev, rank, world, fence):
     buf["workspace"] = None
     ys = Store(reads, MODE_Y_FASTA)
     counts = ys.to_device(dev).count_y(K)
-    if world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(counts)              # every rank masks the same rows: y of all ranks' reads
+    ctx.all_reduce_dev(counts)               # every rank masks the same rows: y of all ranks' reads
     torch.cuda.synchronize()
     T = xs.n_rec_total
     t0 = time.perf_counter()
@@ -153,7 +427,6 @@ def bench_model(args, K, dev, rank, world, fence):
     setup_s = time.perf_counter() - t0
     theta = torch.full((T,), 1.0 / T, dtype=torch.float32, device=dev)
     val = 0.0
-
     xtheta = torch.empty(dm.n_masked, dtype=torch.float32, device=dev)
 
     def step():
@@ -162,30 +435,13 @@ def bench_model(args, K, dev, rank, world, fence):
             val, _ = dm.logp_grad(theta)
         else:                                # column shards: this rank's isoforms are its columns of X
             dm.xtheta_into(theta, xtheta)
-            dist.all_reduce(xtheta)          # RCCL: float32[masked rows], the evaluation's one exchange step
+            ctx.all_reduce_dev(xtheta)       # RCCL: float32[masked rows], the evaluation's one exchange step
             val, _ = dm.grad_from(xtheta)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    _lib.profile(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    table = _lib.profile_table()
-    _lib.profile(False)
-    if world > 1:
-        t = torch.tensor([dt, float(dm.nnz)], dtype=torch.float64, device=dev)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt, nnz_all = float(tmax[0].item()), float(t[1].item())
-    else:
-        nnz_all = float(dm.nnz)
+    dt, table = timed(ctx, step)
+    dt, nnz_all = ctx.all_max_sum(dt, dm.nnz)
     if rank != 0:
-        return
+        return None
     ms_per_step = dt / args.steps * 1e3
     nnz, n_m = dm.nnz, dm.n_masked
     kernel_bytes = {      # per launch: 8 bytes per non-zero, row pointers in, one float per row out, the gathered vector once
@@ -193,28 +449,19 @@ def bench_model(args, K, dev, rank, world, fence):
         "k_spmv<w.x>": 8 * nnz + 4 * (T + 1) + 4 * T + 4 * n_m,
         "k_logp_terms": (4 + 4 + 4) * n_m,
     }
-    dom = max((r for r in table if r[0] in kernel_bytes), key=lambda r: r[1])
-    avg_ms = dom[1] / dom[2]
-    ach = kernel_bytes[dom[0]] / (avg_ms * 1e-3) / 1e9
     path_bytes = sum(kernel_bytes.values())
-    traffic = None            # measured by rocprofv3 PMC passes of this same command (tools/pmc.sh + tools/pmc_traffic.py)
-    tpath = os.path.join(ROOT, "kmers_amd", "data", "pmc_traffic.json")
-    if (args.records, args.bases, args.reads) == (170_000, 400_000_000, 10_000_000) and os.path.exists(tpath):
-        with open(tpath) as f:
-            traffic = json.load(f).get(args.workload, {}).get("kernels", {}).get(dom[0], {}).get("bytes")
+    default_size = (args.records, args.bases, args.model_reads) == (170_000, 400_000_000, 10_000_000) and world == 1
     out = {
         "metric": "logp_grad non-zeros/s (X.theta + X^T.(y/X.theta) on the resident X; SURVEY.md 8f row 4)",
         "value": 2 * nnz_all * args.steps / dt, "unit": "non-zeros/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 in, f64 accumulate", "data": "synthetic",
-        "config": {"workload": f"logp_grad K={K}: X of {T} isoforms / {xs.n_bases / 1e6:.0f} Mbases, y of {args.reads} "
-                               f"simulated 100 bp reads per GPU ({args.workload}"
+        "config": {"workload": f"logp_grad K={K}: X of {T} isoforms / {xs.n_bases / 1e6:.0f} Mbases, y of {args.model_reads} "
+                               f"simulated 100 bp reads per GPU (g{K}"
                                + ("; column shards, xtheta all-reduced)" if world > 1 else ")"),
                    "K": K, "nnz_x": nnz_x, "masked_rows": n_m, "nnz_xnnz": nnz, "val": val,
                    "model_setup_s": round(setup_s, 3), "parallelism": f"column-shards{world}"},
-        "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_ms": round(avg_ms, 4),
-                     "launches_per_step": dom[2] // max(args.steps, 1), "algorithmic_bytes": int(kernel_bytes[dom[0]])},
+        "roofline": roofline(table, kernel_bytes, path_bytes, ms_per_step, args.steps, f"g{K}", default_size),
         "path": {"algorithmic_bytes": int(path_bytes),
                  "achieved_GBs": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 1)},
         "kernels_ms": {r[0]: round(r[1] / args.steps, 4) for r in table},
@@ -242,7 +489,20 @@ def bench_model(args, K, dev, rank, world, fence):
                                              f"|grad|_1 {float(np.abs(g).sum()):.4f}"}
         except Exception as e:
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
-    print(json.dumps(out))
+    return out
+
+
+def run_workload(ctx, tag):
+    kind, K = tag[0], int(tag[1:])
+    if kind == "g":
+        return run_model(ctx, K)
+    out = run_x(ctx, K, tag) if kind == "x" else run_y(ctx, K, tag)
+    if out is not None and ctx.world == 1 and not ctx.args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(ctx.args, K, kind == "x")
+        except Exception as e:  # the baseline must never hide the GPU number
+            out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    return out
 
 
 def main():
@@ -250,166 +510,27 @@ def main():
     if os.environ.get("KMERS_BENCH_WATCHDOG"):     # seconds: dump every thread's stack and exit instead of hanging
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["KMERS_BENCH_WATCHDOG"]), exit=True)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    kind_x = args.workload[0] == "x"
-    K = int(args.workload[1:])
-
-    import torch
-    import torch.distributed as dist
-    from kmers_amd import _lib
-    from kmers_amd.store import MODE_X, MODE_Y_FASTA, Store
-
-    # KMERS_BENCH_REHEARSAL=1: several ranks on ONE GPU over gloo (RCCL refuses two ranks on a device) -- to rehearse the
-    # multi-rank control flow on a one-GPU box; never a measurement
-    rehearsal = os.environ.get("KMERS_BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-
-    if args.workload[0] == "g":
-        def fence0():
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-        bench_model(args, K, dev, rank, world, fence0)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
-    iso, reads = make_inputs(args, rank, want_reads=not kind_x)
-    st = Store(iso if kind_x else reads, MODE_X if kind_x else MODE_Y_FASTA)
-    ds = st.to_device(dev)
-    windows = st.n_windows(K)
-    n_bases, n_rec, n_pos = st.n_bases, st.n_rec, st.n_pos
-    M = 4 ** K
-    instances = int(ds.count_y(K).sum().item())      # valid windows (entries the X path sorts); not timed
-
-    if kind_x:
-        buf = ds.x_buffers(K, windows)
-        nnz = 0
-
-        def step():
-            nonlocal nnz
-            nnz = ds.build_x(buf)
-    else:
-        counts = torch.zeros(M, dtype=torch.int32, device=dev)
-        y_ws = ds.y_workspace(K)             # K >= 9: partition scratch, kept across steps
-
-        def step():
-            counts.zero_()
-            ds.count_y(K, counts, workspace=y_ws)
-            if world > 1:
-                dist.all_reduce(counts)      # RCCL ring over xGMI: the reference's shared-array "+=" across GPUs
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    _lib.profile(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    table = _lib.profile_table()
-    _lib.profile(False)
-
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    w = torch.tensor([float(windows)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(w, op=dist.ReduceOp.SUM)
-    dt_max, windows_all = float(t.item()), float(w.item())
-
-    if rank == 0:
-        ms_per_step = dt_max / args.steps * 1e3
-        value = windows_all * args.steps / dt_max
-        # ---- algorithmic bytes per rank
-        B = n_bases
-        E = instances
-        if kind_x:
-            path_bytes = B / 4 + B / 8 + 8 * (n_rec + 1) + nnz * 12 + 8 * (M + 1)
-            es = 4 if (K <= 8 and n_rec <= 1 << 24) else 8      # bytes per partition entry
-            # what each kernel has to move at minimum for its own job (per launch)
-            kernel_bytes = {
-                "k_hist_bases": n_pos * 3 / 8 + 8 * (n_rec + 1),
-                "k_scatter<bases>": n_pos * 3 / 8 + 8 * (n_rec + 1) + es * E,
-                "k_hist_entries": es * E,
-                "k_scatter<entries>": 2 * es * E,
-                "k_rle": es * E + 12 * nnz + 8 * (M + 1),
-            }
-        else:
-            path_bytes = B / 4 + B / 8 + 4 * M
-            kernel_bytes = {
-                "k_count_y_lds": n_pos * 3 / 8 * (2 if K == 8 else 1) + 4 * M,
-                "k_count_y_global": n_pos * 3 / 8 + 8 * E,
-                "k_hist_words_y": n_pos * 3 / 8,
-                "k_scatter<bases,y>": n_pos * 3 / 8 + (2 if K <= 12 else 4) * E,   # 2-byte payloads with one pass
-                "k_hist_entries": 4 * E,
-                "k_scatter<entries>": 8 * E,
-                "k_count_y_sorted": (2 if K <= 12 else 4) * E + 8 * M,
-            }
-        dom = max((r for r in table if r[0] in kernel_bytes), key=lambda r: r[1], default=None)
-        # HBM traffic per launch measured with rocprofv3 PMC passes of this same command (tools/pmc.sh +
-        # tools/pmc_traffic.py; counters cannot be read from inside the process), default sizes only
-        traffic = None
-        default_size = (args.records, args.bases, args.reads) == (170_000, 400_000_000, 10_000_000)
-        tpath = os.path.join(ROOT, "kmers_amd", "data", "pmc_traffic.json")
-        if dom is not None and default_size and os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get(args.workload, {}).get("kernels", {}).get(dom[0], {}).get("bytes")
-        roof = None
-        if dom is not None:
-            avg_ms = dom[1] / dom[2]
-            ach = kernel_bytes[dom[0]] / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom[0], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_ms": round(avg_ms, 4),
-                    "launches_per_step": dom[2] // max(args.steps, 1), "algorithmic_bytes": int(kernel_bytes[dom[0]])}
-        else:
-            ach = path_bytes / (ms_per_step * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_count_y", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_ms": round(ms_per_step, 4),
-                    "algorithmic_bytes": int(path_bytes)}
-        path_gbs = path_bytes / (ms_per_step * 1e-3) / 1e9
-        out = {
-            "metric": METRIC, "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"{'transcriptome_to_x' if kind_x else 'reads->y'} K={K}: "
-                                   f"{n_rec} records / {n_bases / 1e6:.0f} Mbases per GPU "
-                                   f"({'BASELINE.json configs[1]' if args.workload == 'x8' else args.workload})",
-                       "K": K, "records_per_gpu": n_rec, "bases_per_gpu": n_bases, "kmers_per_gpu": windows,
-                       "valid_instances_per_gpu": instances, "nnz_per_gpu": (nnz if kind_x else None),
-                       "parallelism": f"shards{world}"},
-            "roofline": roof,
-            "path": {"algorithmic_bytes": int(path_bytes), "bytes_per_kmer": round(path_bytes / max(windows, 1), 3),
-                     "achieved_GBs": round(path_gbs, 1), "frac_of_hbm_peak": round(path_gbs / HBM_PEAK_GBS, 4)},
-            "kernels_ms": {r[0]: round(r[1] / args.steps, 4) for r in table},
-        }
-        if world == 1 and not args.no_cpu_baseline:
+    ctx = Ctx(args)
+    out = run_workload(ctx, args.workload)
+    if not args.explicit and not args.only:
+        also = []
+        for tag in ALSO:
             try:
-                out["cpu_baseline"] = cpu_baseline(args, K, kind_x)
-            except Exception as e:  # the baseline must never hide the GPU number
-                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+                line = run_workload(ctx, tag)
+            except Exception as e:                 # a side workload must never hide the headline
+                line = {"config": {"workload": tag}, "error": repr(e)}
+            if line is not None:
+                line["workload"] = tag
+                also.append(line)
+        if out is not None:
+            out["also"] = also
+    if ctx.rank == 0:
+        if ctx.rehearsal:
+            out["rehearsal"] = "several ranks on one GPU over gloo: control flow only, not a measurement"
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if ctx.world > 1:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -154,6 +154,16 @@ int kmers_hip_debug_stamps(unsigned long long *out16, int reset);
 int kmers_csr_merge(int n_parts, uint64_t n_rows, const float *const data[], const uint64_t *const row_ind[],
                     const uint64_t *const col_ind[], float *out_data, uint64_t *out_row_ind, uint64_t *out_col_ind);
 
+/* One rank's part of the same interleave when every rank writes into ONE shared output (multi-process, POSIX shared
+ * memory): this rank's CSR (row_ind u64[n_rows + 1], data, col_ind) goes to
+ *   out[global_row_ind[r] + (before[r + 1] - before[r]) ...]  for every row r,
+ * where global_row_ind = sum over ranks of row_ind and before = sum of row_ind over the ranks in front of this one (both
+ * u64[n_rows + 1]; kmers_amd.distributed.concat_x_shards gets them from one all-reduce and a prefix over the ranks).
+ * out_row_ind, when not NULL, receives global_row_ind (rank 0).  Host memory; all host threads. */
+int kmers_csr_place(uint64_t n_rows, const uint64_t *row_ind, const uint64_t *before, const uint64_t *global_row_ind,
+                    const float *data, const uint64_t *col_ind, float *out_data, uint64_t *out_col_ind,
+                    uint64_t *out_row_ind);
+
 /* ---- X as the reference's .npz --------------------------------------------- */
 
 /* Write the CSR arrays of the ABI as the uncompressed scipy .npz that the reference's transcriptome_to_x saves

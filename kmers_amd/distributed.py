@@ -5,10 +5,15 @@
      every rank counts its range into a private int32[4^K] in HBM; ONE all-reduce(sum) combines them.  Integer
      sums are order-independent, so the result is bit-identical to the single-GPU one.
   X  records (columns) are partitioned the same way; columns are independent, so there is no reduction: every
-     rank builds the CSR of its column range (global column numbers via first_col) and rank 0 interleaves the
-     per-rank CSRs row by row (kmers_csr_merge), which keeps columns ascending inside each row.
+     rank builds the CSR of its column range (global column numbers via first_col).  For the host-side whole the
+     per-row counts are combined with one all-reduce and an exclusive prefix over the ranks, and every rank writes its
+     rows in place in one shared-memory CSR (concat_x_shards); merge_csr_parts (kmers_csr_merge) interleaves parts
+     that are already on one host.
 """
 import ctypes as C
+import itertools
+import os
+import tempfile
 
 import numpy as np
 
@@ -61,6 +66,100 @@ def count_y_sharded(files, K, fastq=False, device=None, count_fn=None):
     return counts.cpu().numpy()
 
 
+_SHM_DIR = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+_shm_serial = itertools.count()
+
+
+def _rank_prefix(row, dist, rank, world):
+    """Exclusive prefix over the ranks of a tensor (Hillis-Steele: ceil(log2 world) rounds of one send and one receive
+    of the whole tensor per rank; an all-gather would hold `world` copies -- 16 GB of row pointers at K=14 on 8 GPUs)."""
+    import torch
+    inc = row.clone()
+    d = 1
+    while d < world:
+        ops, recv = [], None
+        if rank + d < world:
+            ops.append(dist.P2POp(dist.isend, inc.clone(), rank + d))
+        if rank - d >= 0:
+            recv = torch.empty_like(inc)
+            ops.append(dist.P2POp(dist.irecv, recv, rank - d))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if recv is not None:
+            inc += recv
+        d *= 2
+    return inc - row
+
+
+def concat_x_shards(data, col_ind, row_ind, nnz, n_rows, gloo=False):
+    """The host-side concatenation of north_star's multi-GPU X: every rank holds the CSR of its column range (torch
+    tensors on its GPU, or on the CPU in the gloo tests; global column numbers; row_ind int64[n_rows + 1]); rank 0
+    returns (data f32, row_ind u64, col_ind u64) of the whole matrix as numpy arrays, the others None.
+
+    SURVEY.md section 8e's scheme, no pickling and no merge on one rank:
+      * the global row pointer is ONE all-reduce (sum) of the per-rank row pointers (the per-row counts combined);
+      * rank g's entries of row r go to  global[r] + (entries of row r on ranks < g), an exclusive prefix over the
+        ranks of the same vector (_rank_prefix);
+      * every rank copies its shard to the host over its own PCIe link and writes its rows in place in one POSIX
+        shared-memory CSR (kmers_csr_place, all host threads), so the copies and the placement run on all ranks at once."""
+    import torch
+    dist = _dist()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lib = _lib.handle()
+    assert row_ind.dtype == torch.int64 and row_ind.numel() == n_rows + 1
+    on_gpu = row_ind.is_cuda and not gloo
+    comm = (lambda t: t) if on_gpu else (lambda t: t.cpu())      # the tensors the collectives run on
+    row_c = comm(row_ind).contiguous()
+    glob = row_c.clone()
+    dist.all_reduce(glob, op=dist.ReduceOp.SUM)
+    before = _rank_prefix(row_c, dist, rank, world)
+    total = int(glob[-1].item())
+    # this rank's shard on the host (pinned when it comes from the GPU: the copy then runs at the link's rate)
+    pinned = []
+
+    def to_host(t, n):
+        if not t.is_cuda:
+            return t[:n].contiguous().numpy()
+        h = torch.empty(n, dtype=t.dtype, pin_memory=True)
+        h.copy_(t[:n], non_blocking=True)
+        pinned.append(h)
+        return h.numpy()                     # valid after the synchronize below
+
+    h_data, h_col = to_host(data, nnz), to_host(col_ind, nnz)
+    h_row, h_glob, h_before = to_host(row_ind, n_rows + 1), to_host(glob, n_rows + 1), to_host(before, n_rows + 1)
+    if pinned:
+        torch.cuda.synchronize()
+    # the shared output: three files in /dev/shm mapped by every rank, unlinked as soon as all ranks have written (the
+    # mapping rank 0 returns keeps the pages until its arrays go)
+    shapes = ((max(total, 1), np.float32), (max(total, 1), np.uint64), (n_rows + 1, np.uint64))
+    base = [None]
+    if rank == 0:
+        base[0] = os.path.join(_SHM_DIR, "kmers_x_%d_%d" % (os.getpid(), next(_shm_serial)))
+        for i, (n, dt) in enumerate(shapes):
+            with open(base[0] + ".%d" % i, "wb") as f:
+                f.truncate(n * np.dtype(dt).itemsize)
+    dist.broadcast_object_list(base, src=0)           # one short string
+    try:
+        o_data, o_col, o_row = (np.memmap(base[0] + ".%d" % i, dtype=dt, mode="r+", shape=(n,))
+                                for i, (n, dt) in enumerate(shapes))
+        rc = lib.kmers_csr_place(n_rows, h_row.ctypes.data, h_before.ctypes.data, h_glob.ctypes.data, h_data.ctypes.data,
+                                 h_col.ctypes.data, o_data.ctypes.data, o_col.ctypes.data,
+                                 o_row.ctypes.data if rank == 0 else None)
+        dist.barrier()
+    finally:
+        if rank == 0:
+            for i in range(3):
+                try:
+                    os.unlink(base[0] + ".%d" % i)
+                except OSError:
+                    pass
+    _lib.check(rc, "kmers_csr_place")
+    if rank != 0:
+        return None
+    return o_data[:total], o_row, o_col[:total]
+
+
 def build_x_sharded(files, K, L=0, concatenate_subseq=False, device=None, build_fn=None):
     """Rank 0 returns (data, row_ind, col_ind, n_cols) of the whole matrix; other ranks return None.
     build_fn(store, K) -> (data, row_ind, col_ind) numpy replaces the HIP call in CPU tests only."""
@@ -68,20 +167,21 @@ def build_x_sharded(files, K, L=0, concatenate_subseq=False, device=None, build_
     dist = _dist()
     rank, world = dist.get_rank(), dist.get_world_size()
     st = Store(files, MODE_X_CAT if concatenate_subseq else MODE_X, L=L, shard=rank, n_shards=world)
+    M = 4 ** K
     if build_fn is None:
         ds = st.to_device(device or "cuda")
         buf = ds.x_buffers(K, st.n_windows(K))
         nnz = ds.build_x(buf)
-        part = (buf["data"][:nnz].cpu().numpy(), buf["row_ind"].cpu().numpy().view(np.uint64),
-                buf["col_ind"][:nnz].cpu().numpy().view(np.uint64))
+        res = concat_x_shards(buf["data"], buf["col_ind"], buf["row_ind"], nnz, M,
+                              gloo=dist.get_backend() == "gloo")
     else:
-        part = build_fn(st, K)
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object(part, gathered, dst=0)          # host-side concatenation of column shards
+        d, r, c = build_fn(st, K)
+        res = concat_x_shards(torch.from_numpy(np.ascontiguousarray(d, np.float32)),
+                              torch.from_numpy(np.ascontiguousarray(c, np.uint64).view(np.int64)),
+                              torch.from_numpy(np.ascontiguousarray(r, np.uint64).view(np.int64)), int(len(d)), M, gloo=True)
     if rank != 0:
         return None
-    d, r, c = merge_csr_parts(gathered, 4 ** K)
-    return d, r, c, st.n_rec_total
+    return np.asarray(res[0]), np.asarray(res[1]), np.asarray(res[2]), st.n_rec_total
 
 
 class ShardedModel:

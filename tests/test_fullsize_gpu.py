@@ -7,6 +7,14 @@ independent code paths that must agree bit for bit:
   * X at K=14 (four passes, 2^28 rows): same structural checks, and the whole == the interleave of two column shards;
   * y at K=8 (LDS tables), 12 (one partition pass, 2-byte payloads), 14 (two passes) == the plain global-atomics
     kernel; totals == the number of valid windows.
+  * y at K=12 on BASELINE.json configs[3] as written: 10^8 simulated 100 bp reads (kmers_amd.simulate_reads, the reads
+    made in HBM), 1.01e10 positions = five chunks of the partition path == the plain global-atomics kernel; total ==
+    the number of valid windows; the K=14 histogram of the same reads folded to K=12 bounds it from below;
+  * configs[4] on one GPU at full size: X at K=14 and y at K=14 of 10 M reads feed the model; sum(X . theta) over all
+    rows is 1 for any theta on the simplex (columns of X sum to 1), logp_grad agrees with a float64 restatement on a
+    sample of rows / columns taken from the resident arrays, and exponentiated-gradient steps raise the likelihood;
+  * X at K=15 (2^30 rows, 8.6 GB of row pointer): the structural checks, and rows folded by 4 == the K=14 row counts
+    of the windows that extend by one base.
 Inputs are the seeded synthetic files bench.py uses (kmers_amd/synth.py)."""
 import os
 
@@ -120,3 +128,106 @@ def test_y_full_size(full, K, monkeypatch):
     else:
         monkeypatch.setenv("KMERS_Y_ATOMICS", "1")
         assert torch.equal(ds.count_y(K), y)
+
+
+def test_y12_one_hundred_million_simulated_reads(full, monkeypatch):
+    """BASELINE.json configs[3] at its stated size."""
+    import torch
+    from kmers_amd.simulate_reads import simulate_reads_device
+    N, L = 100_000_000, 100
+    ds, info = simulate_reads_device(N, L, 0.1, full["iso"])
+    assert ds.n_rec == N and ds.n_pos == N * (L + 1) and ds.n_pos > 2 * (1 << 31)        # at least three chunks
+    y = ds.count_y(12)
+    total = int(y.sum(dtype=torch.int64))
+    windows = N * (L - 12 + 1)
+    assert 0.99 * windows < total <= windows
+    y14 = ds.count_y(14)
+    t14 = int(y14.sum(dtype=torch.int64))
+    folded = y14.view(4 ** 12, 16).sum(1, dtype=torch.int64)      # every valid 14-mer starts with a valid 12-mer
+    extra = y.long() - folded                                     # the two last 12-mers of a read + 12-mers stopped by an N
+    assert bool((extra >= 0).all()) and 2 * N <= int(extra.sum()) == total - t14 <= 2 * N + total // 1000
+    monkeypatch.setenv("KMERS_Y_ATOMICS", "1")
+    assert torch.equal(ds.count_y(12), y)
+    # the sampled isoform ids and starts are the reference's stream: the histogram of the reads' first 12-mers follows
+    assert info["theta_sampled"].shape[0] == len(info["lengths"]) and abs(float(info["theta_sampled"].sum()) - 1) < 1e-9
+
+
+def test_config4_full_size_build_count_fit(full):
+    """X (K=14) + y (K=14) of the full-size inputs -> the model in HBM -> logp_grad -> a short fit."""
+    import torch
+    from kmers_amd.model import DeviceModel
+    K, M = 14, 4 ** 14
+    xs = Store(full["iso"], MODE_X)
+    dx = xs.to_device()
+    buf = dx.x_buffers(K, xs.n_windows(K))
+    nnz = dx.build_x(buf)
+    buf["workspace"] = None
+    counts = Store(full["reads"], MODE_Y_FASTA).to_device().count_y(K)
+    T = xs.n_rec_total
+    dm = DeviceModel(buf["data"], buf["col_ind"], buf["row_ind"], T, counts)
+    assert dm.n_masked == int((counts > 0).sum()) and 0 < dm.nnz <= nnz
+    dev = counts.device
+    g = torch.Generator(device="cpu").manual_seed(3)
+    theta = torch.rand(T, generator=g, dtype=torch.float64).to(dev)
+    theta = (theta / theta.sum()).float()
+    # (1) sum over ALL rows of X . theta = sum_t theta_t * (column sum = 1 where the isoform has a k-mer)
+    data, col = buf["data"][:nnz], buf["col_ind"][:nnz]
+    live = torch.zeros(T, dtype=torch.bool, device=dev)
+    live[col] = True
+    assert abs(float((data.double() * theta.double()[col]).sum()) - float(theta.double()[live].sum())) < 1e-6
+    # (2) logp_grad against float64 on the masked rows, from the resident arrays (torch as the checker)
+    val, grad = dm.logp_grad(theta)
+    row = buf["row_ind"]
+    rows_of = torch.repeat_interleave(torch.arange(M, device=dev), row[1:] - row[:-1])
+    mask = counts > 0
+    keep = mask[rows_of]
+    r, c, d = rows_of[keep], col[keep], data[keep].double()
+    del rows_of, keep
+    xt = torch.zeros(M, dtype=torch.float64, device=dev).index_add_(0, r, d * theta.double()[c])
+    ynorm = counts.double() / float(counts.sum(dtype=torch.int64))
+    want_val = float((ynorm[mask] * torch.log(xt[mask])).sum())
+    w = torch.zeros(M, dtype=torch.float64, device=dev)
+    w[mask] = ynorm[mask] / xt[mask]
+    want_grad = torch.zeros(T, dtype=torch.float64, device=dev).index_add_(0, c, d * w[r])
+    assert abs(val - want_val) < 1e-5 * abs(want_val)
+    g_dev = torch.as_tensor(grad, device=dev).double()
+    assert float((g_dev - want_grad).abs().max()) < 2e-4 * float(want_grad.abs().max())
+    del r, c, d, xt, w
+    # (3) exponentiated-gradient steps (kmerexpr/exp_grad_solver.py:60-64, default step) raise the likelihood
+    theta = torch.full((T,), 1.0 / T, dtype=torch.float32, device=dev)
+    v0, g0 = dm.logp_grad(theta)
+    lr = 2 ** -0.5 / float(torch.as_tensor(g0).abs().max())
+    vals = [v0]
+    for _ in range(8):
+        v, gr = dm.logp_grad(theta)
+        gr = torch.as_tensor(gr, device=dev)
+        theta = theta * torch.exp(lr * (gr - gr.max()))
+        theta = theta / theta.sum()
+        vals.append(dm.logp_grad(theta, nograd=True))
+    assert vals[-1] > v0 and sum(b > a for a, b in zip(vals, vals[1:])) >= 6, vals
+
+
+def test_x15_structure(full):
+    """K=15: 2^30 rows.  Structural checks, and against K=14: a 15-mer's first 14 bases are a 14-mer of the same isoform,
+    so the rows of X15 folded by 4 have at most the entries of X14's rows, and every isoform with a 15-mer has a 14-mer."""
+    import torch
+    K, M = 15, 4 ** 15
+    st = Store(full["iso"], MODE_X)
+    ds = st.to_device()
+    buf = ds.x_buffers(K, st.n_windows(K))
+    nnz = ds.build_x(buf)
+    live15 = _csr_checks(torch, buf, nnz, M, st.n_rec)
+    y = Store(full["iso"], MODE_Y_FASTA).to_device().count_y(K)
+    assert torch.equal(y > 0, buf["row_ind"][1:] > buf["row_ind"][:-1])
+    per14 = (buf["row_ind"][4::4] - buf["row_ind"][:-4:4]).clone()       # entries of the 4 extensions of each 14-mer
+    del buf, y
+    torch.cuda.empty_cache()
+    b14 = ds.x_buffers(14, st.n_windows(14))
+    n14 = ds.build_x(b14)
+    rows14 = b14["row_ind"][1:] - b14["row_ind"][:-1]
+    assert nnz <= 4 * n14
+    assert bool(((per14 > 0) <= (rows14 > 0)).all())                     # a 15-mer row implies its 14-mer row
+    assert bool((per14 <= 4 * rows14).all())
+    live14 = torch.zeros(st.n_rec, dtype=torch.bool, device=ds.device)
+    live14[b14["col_ind"][:n14]] = True
+    assert bool((live15 <= live14).all())

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """HBM traffic per kernel launch from the FETCH_SIZE / WRITE_SIZE passes of tools/pmc.sh, corrected as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts 128-byte requests as 64: doubled;
-both counters are in KiB).  Writes kmers_amd/data/pmc_traffic.json, which bench.py quotes as roofline.traffic.
+both counters are in KiB).  Writes profiles/pmc_traffic.json, stamped with the hash of the kernel sources the passes ran
+(bench.kernels_sha); bench.py quotes it as roofline.traffic only while that hash is the tree's.
 
     tools/pmc_traffic.py gpurun_out/pmc3 x8
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import re
@@ -19,6 +21,9 @@ LABEL = [  # kernel symbol (regex) -> the label of bench.py's per-kernel table
     (r"k_spmv<1", "k_spmv<w.x>"),
     (r"k_logp_terms", "k_logp_terms"),
     (r"k_rle<", "k_rle"),
+    (r"k_dd<false", "k_dd<hist>"),
+    (r"k_dd<true", "k_dd<scatter>"),
+    (r"k_final_scatter", "k_final_scatter"),
     (r"k_scatter<true, unsigned int, true|k_yscatter", "k_scatter<bases,y>"),
     (r"k_scatter<true", "k_scatter<bases>"),
     (r"k_scatter<false", "k_scatter<entries>"),
@@ -45,10 +50,15 @@ for lab, c in acc.items():
         write = 1024.0 * sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
         out[lab] = {"bytes": int(fetch + write), "fetch_bytes": int(fetch), "write_bytes": int(write),
                     "launches_sampled": len(c["FETCH_SIZE"])}
-path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kmers_amd", "data", "pmc_traffic.json")
-os.makedirs(os.path.dirname(path), exist_ok=True)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sha = hashlib.sha256()
+for f in ("kernels.hip", "model.hip"):                 # the same hash as bench.kernels_sha()
+    with open(os.path.join(ROOT, "kmers_amd", "csrc", f), "rb") as fh:
+        sha.update(fh.read())
+path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 allw = json.load(open(path)) if os.path.exists(path) else {}
-allw[workload] = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH doubled (gfx950), KiB -> bytes; "
+allw[workload] = {"kernels_sha": sha.hexdigest()[:16],
+                  "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH doubled (gfx950), KiB -> bytes; "
                             "mean per launch", "kernels": out}
 json.dump(allw, open(path, "w"), indent=1, sort_keys=True)
 print(json.dumps(allw[workload], indent=1))
