@@ -14,7 +14,7 @@ With no --workload the line is x8 and carries an `also` list with x14, y12 and y
 its own ms_per_step, roofline and cpu_baseline (--only: the headline alone).
 
 N > 1 (one process per GPU, torchrun): STRONG scaling of the same job.  The ONE transcriptome is split into N contiguous
-record ranges (kmers_store_ingest's shard arguments) and rank r builds the CSR of its columns; the ONE set of reads is
+record ranges (kmers_store_ingest_bytes: rank r parses only its N-th of the file's bytes) and rank r builds the CSR of its columns; the ONE set of reads is
 split the same way and the histograms are summed with one RCCL all-reduce inside the timed step.  X needs no data-path
 collective; what north_star calls "concatenated on the host" is timed once, apart, after the steps (`concat`: every rank
 copies its shard over its own PCIe link and places it in a shared host buffer, kmers_amd.distributed.concat_x_shards)
@@ -158,7 +158,11 @@ class Ctx:
         """This rank's shard (contiguous record range) of the ONE transcriptome, host and device side."""
         if self._xstore is None:
             from kmers_amd.store import MODE_X, Store
-            st = Store(self.iso_file(), MODE_X, shard=self.rank, n_shards=self.world)
+            if self.world > 1:       # rank r parses only its byte range of the file (kmers_store_ingest_bytes)
+                from kmers_amd.distributed import ingest_sharded
+                st = ingest_sharded(self.iso_file(), MODE_X)
+            else:
+                st = Store(self.iso_file(), MODE_X)
             self._xstore = (st, st.to_device(self.dev))
         return self._xstore
 

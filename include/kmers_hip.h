@@ -44,6 +44,9 @@ extern "C" {
 #define KMERS_MODE_X_CAT 1    /* fasta_to_kmers_csr_cat_subseq: one record per file                              */
 #define KMERS_MODE_Y_FASTA 2  /* fasta_count_kmers:             one record per non-PREDICTED FASTA record        */
 #define KMERS_MODE_Y_FASTQ 3  /* fastq_gz_count_kmers:          one record per file (reads joined)               */
+#define KMERS_MODE_FASTA_PY 4 /* the isoforms as kmerexpr/fasta.py reads them for simulate_reads (python text-mode lines,
+                                 strip() on both sides, records only at '>' lines, PREDICTED and len >= L filters;
+                                 reference kmerexpr/fasta.py:19-46, simulate_reads.py:78-92); ASCII files only */
 
 /* A packed sequence store in host memory (pinned when a HIP device is present).
  *
@@ -61,9 +64,19 @@ typedef struct kmers_store kmers_store;
 
 /* Parse `n_files` files under the rules of `mode` with `KMER_NUM_THREADS` host threads (default: all cores,
  * at most 64) and pack shard `shard` of `n_shards` (contiguous record ranges balanced by positions; pass
- * 0, 1 for everything).  L is used by the two X modes only.  Returns 0 or KMERS_ERR_OPEN / _BAD_ARG / _NOMEM. */
+ * 0, 1 for everything).  L is used by the two X modes and KMERS_MODE_FASTA_PY.  Returns 0 or KMERS_ERR_OPEN / _BAD_ARG / _NOMEM. */
 int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int shard, int n_shards,
                        kmers_store **out);
+/* The same for multi-process ingest where no rank looks at the whole input: shard `shard` is the records whose header
+ * lies in bytes [T shard / n_shards, T (shard + 1) / n_shards) of the files laid end to end (T bytes), and only those
+ * bytes are scanned (plus the tail of the range's last record).  Record numbers are local (first_rec 0, n_rec_total =
+ * n_rec) until kmers_store_set_numbering() is given the sum of the earlier shards' n_rec and the total (one small
+ * all-gather, kmers_amd.distributed.ingest_sharded).  The concatenation of the shards in order is the whole list, so
+ * column numbers are the single-process ones.  KMERS_MODE_X, _Y_FASTA and _FASTA_PY (the other two modes have one
+ * record per file: shard those with kmers_store_ingest). */
+int kmers_store_ingest_bytes(int n_files, const char *fnames[], int mode, int L, int shard, int n_shards,
+                             kmers_store **out);
+void kmers_store_set_numbering(kmers_store *s, uint64_t first_rec, uint64_t n_rec_total);
 void kmers_store_free(kmers_store *s);
 
 uint64_t kmers_store_n_pos(const kmers_store *s);         /* positions in this shard (bases + separators)      */
@@ -223,7 +236,7 @@ int kmers_hip_model_logp_grad(kmers_model *m, const float *d_theta, int nograd, 
 /* ---- simulated reads straight into a packed store ------------------------------------ */
 
 /* The copying step of the reference's simulate_reads (kmerexpr/simulate_reads.py:111-121: read n = L bases of isoform
- * iso[n] from start[n]) on the device: the transcriptome store (kmers_store_ingest, KMERS_MODE_X with the same L, so
+ * iso[n] from start[n]) on the device: the transcriptome store (kmers_store_ingest, KMERS_MODE_FASTA_PY with the same L, so
  * that its records are the reference's isoform list) in, a reads store out -- read n at positions
  * [n (L + 1), n (L + 1) + L) plus one separator, the layout kmers_hip_count_y takes with n_pos = n_reads (L + 1).
  * Output arrays: at least n_pos / 16 + 4 and n_pos / 32 + 4 words (KMERS_ERR_WORKSPACE), fully written (padding

@@ -65,6 +65,9 @@ def handle():
     vp = C.c_void_p
     lib.kmers_store_ingest.restype = C.c_int
     lib.kmers_store_ingest.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.kmers_store_ingest_bytes.restype = C.c_int
+    lib.kmers_store_ingest_bytes.argtypes = lib.kmers_store_ingest.argtypes
+    lib.kmers_store_set_numbering.restype, lib.kmers_store_set_numbering.argtypes = None, [vp, C.c_uint64, C.c_uint64]
     lib.kmers_store_free.restype, lib.kmers_store_free.argtypes = None, [vp]
     for name in ("n_pos", "n_rec", "n_rec_total", "first_rec", "n_bases"):
         f = getattr(lib, "kmers_store_" + name)

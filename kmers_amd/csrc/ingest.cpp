@@ -16,6 +16,15 @@
 //     (compared as unsigned in the reference, so a negative L skips everything);
 //   * on the two X paths a sequence ends at its first NUL byte: the reference hands sequence.data() to a
 //     function taking const std::string& (src/libkmers.cpp:233), which re-measures it with strlen.
+//
+// KMERS_MODE_FASTA_PY: the OTHER FASTA reader of the reference, kmerexpr/fasta.py:19-46 (python text mode), which its
+// read simulator uses for the isoforms (kmerexpr/simulate_reads.py:78-92).  Its rules differ and are kept as they are:
+//   * a line ends at '\n', "\r\n" or a lone '\r' (open(path, "r") translates them all);
+//   * records start only at lines whose first byte is '>'; whatever precedes the first such line is ignored; if the
+//     FIRST header is empty after '>' and rstrip(), the file holds no records (fasta.py:32-33);
+//   * every sequence line is strip()ped on both sides of python's ASCII whitespace (9-13, 28-32); inner bytes stay;
+//   * nothing ends at a NUL; a record is kept when its header does not contain "PREDICTED" and len >= L (signed);
+//   * bytes >= 0x80 are refused (KMERS_ERR_BAD_ARG): python would decode them (or raise), one character per sequence.
 #include "kmers_hip.h"
 #include "store.hpp"
 
@@ -145,6 +154,7 @@ struct Piece {
     uint64_t off;        // offset inside that record
     uint64_t take;       // bases to take
     bool lines;          // true: walk FASTA lines, false: raw bytes
+    bool py = false;     // lines follow kmerexpr/fasta.py (universal newlines, strip() on both sides)
 };
 
 // A growing array of trivially copyable T without value-initialisation (10^7 read records make std::vector's
@@ -214,49 +224,136 @@ inline const uint8_t *find_nl(const uint8_t *p, const uint8_t *end) {
     return r ? (const uint8_t *)r : end;
 }
 
+// ---- kmerexpr/fasta.py line rules
+inline bool py_space(uint8_t c) { return (c >= 9 && c <= 13) || (c >= 28 && c <= 32); }   // str.strip() on ASCII text
+inline const uint8_t *find_eol_py(const uint8_t *p, const uint8_t *end) {                 // first '\n' or '\r'
+    for (; p < end; ++p)
+        if (*p == '\n' || *p == '\r') return p;
+    return end;
+}
+// the stripped extent of one line [p, e)
+inline void strip_py(const uint8_t *&p, const uint8_t *&e) {
+    while (p < e && py_space(*p)) ++p;
+    while (e > p && py_space(e[-1])) --e;
+}
+
 bool header_has_predicted(const uint8_t *h, size_t n) {
     return n >= 9 && memmem(h, n, "PREDICTED", 9) != nullptr;
 }
 
-// Header offsets of a file: offset 0 (unless line 0 is empty, which ends the file at once) and every
-// offset that follows a '\n' and holds '>'.
-void find_headers(const FileView &f, std::vector<size_t> &hdrs) {
+// Header offsets of a file inside the byte range [lo, hi): offset 0 (unless line 0 is empty, which ends the file at
+// once) and every offset that follows a '\n' and holds '>'.
+void find_headers(const FileView &f, size_t lo, size_t hi, std::vector<size_t> &hdrs) {
     hdrs.clear();
-    if (f.n == 0 || f.p[0] == '\n') return;
+    if (f.n == 0 || f.p[0] == '\n' || lo >= hi) return;
     const size_t grain = 4u << 20;
-    const size_t n_chunks = (f.n + grain - 1) / grain;
+    const size_t n_chunks = (hi - lo + grain - 1) / grain;
     std::vector<std::vector<size_t>> part(n_chunks);
-    parallel_for(n_chunks, 1, [&](size_t lo, size_t hi) {
-        for (size_t c = lo; c < hi; ++c) {
-            const uint8_t *a = f.p + c * grain;
-            const uint8_t *b = f.p + std::min(f.n, (c + 1) * grain);
-            const uint8_t *last = f.p + f.n - 1;  // a '\n' here has nothing after it
+    parallel_for(n_chunks, 1, [&](size_t c0, size_t c1) {
+        for (size_t c = c0; c < c1; ++c) {
+            // a header at offset x is found through the '\n' at x - 1: scan [a - 1, b - 1)
+            const size_t xa = lo + c * grain, xb = std::min(hi, xa + grain);
+            const uint8_t *a = f.p + (xa ? xa - 1 : 0);
+            const uint8_t *b = f.p + (xb - 1);
             auto &out = part[c];
+            if (xa == 0) out.push_back(0);          // the first line is a header whatever it starts with
             while (a < b) {
                 const uint8_t *nl = (const uint8_t *)memchr(a, '\n', (size_t)(b - a));
                 if (!nl) break;
-                if (nl < last && nl[1] == '>') out.push_back((size_t)(nl + 1 - f.p));
+                if (nl[1] == '>') out.push_back((size_t)(nl + 1 - f.p));
                 a = nl + 1;
             }
         }
     });
-    std::vector<size_t> at(n_chunks + 1, 1);  // slot 0 is offset 0
-    for (size_t c = 0; c < n_chunks; ++c) at[c + 1] = at[c] + part[c].size();
-    hdrs.resize(at[n_chunks]);
-    hdrs[0] = 0;
-    parallel_for(n_chunks, 1, [&](size_t lo, size_t hi) {
-        for (size_t c = lo; c < hi; ++c)
-            if (!part[c].empty()) memcpy(&hdrs[at[c]], part[c].data(), part[c].size() * sizeof(size_t));
-    });
+    for (auto &v : part) hdrs.insert(hdrs.end(), v.begin(), v.end());
 }
 
-bool analyse_records(const FileView &f, const std::vector<size_t> &hdrs, bool want_nul, RawVec<RecInfo> &recs) {
+// The first header at or after `from` (f.n if none): where the last record of a byte range ends.
+size_t next_header(const FileView &f, size_t from, bool py) {
+    if (from >= f.n) return f.n;
+    if (from == 0) from = 1;
+    const uint8_t *q = f.p + from, *e = f.p + f.n;
+    while (q < e) {
+        const uint8_t *g = (const uint8_t *)memchr(q, '>', (size_t)(e - q));
+        if (!g) break;
+        if (g[-1] == '\n' || (py && g[-1] == '\r')) return (size_t)(g - f.p);
+        q = g + 1;
+    }
+    return f.n;
+}
+
+// kmerexpr/fasta.py: every '>' at the start of a line (offset 0, or after '\n' or '\r') inside [lo, hi), none if the
+// file's first header is empty.  Returns false when [lo, hi) holds a byte >= 0x80.
+bool find_headers_py(const FileView &f, size_t lo, size_t hi, std::vector<size_t> &hdrs) {
+    hdrs.clear();
+    if (f.n == 0 || lo >= hi) return true;
+    const size_t grain = 4u << 20;
+    const size_t n_chunks = (hi - lo + grain - 1) / grain;
+    std::vector<std::vector<size_t>> part(n_chunks);
+    std::atomic<bool> high{false};
+    parallel_for(n_chunks, 1, [&](size_t c0, size_t c1) {
+        for (size_t c = c0; c < c1; ++c) {
+            const size_t a = lo + c * grain, b = std::min(hi, a + grain);
+            uint8_t any = 0;
+            for (size_t i = a; i < b; ++i) any |= f.p[i];
+            if (any & 0x80) high.store(true, std::memory_order_relaxed);
+            const uint8_t *q = f.p + a, *e = f.p + b;
+            while (q < e) {
+                const uint8_t *g = (const uint8_t *)memchr(q, '>', (size_t)(e - q));
+                if (!g) break;
+                const size_t at = (size_t)(g - f.p);
+                if (at == 0 || f.p[at - 1] == '\n' || f.p[at - 1] == '\r') part[c].push_back(at);
+                q = g + 1;
+            }
+        }
+    });
+    if (high.load()) return false;
+    // fasta.py:29-33: an empty first header ends the generator before any record -- whichever range it lies in
+    const size_t first = (f.p[0] == '>') ? 0 : next_header(f, 0, true);
+    if (first < f.n) {
+        const uint8_t *h = f.p + first + 1, *e = find_eol_py(h, f.p + f.n);
+        while (e > h && py_space(e[-1])) --e;
+        if (e == h) return true;
+    }
+    for (auto &v : part) hdrs.insert(hdrs.end(), v.begin(), v.end());
+    return true;
+}
+
+bool analyse_records_py(const FileView &f, const std::vector<size_t> &hdrs, size_t tail_end, RawVec<RecInfo> &recs) {
     recs.n = 0;
     if (hdrs.size() && !recs.grow(hdrs.size())) return false;
     parallel_for(hdrs.size(), 256, [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
             const uint8_t *h = f.p + hdrs[i];
-            const uint8_t *end = f.p + ((i + 1 < hdrs.size()) ? hdrs[i + 1] : f.n);
+            const uint8_t *end = f.p + ((i + 1 < hdrs.size()) ? hdrs[i + 1] : tail_end);
+            const uint8_t *he = find_eol_py(h, end);
+            RecInfo r;
+            r.predicted = header_has_predicted(h + 1, (size_t)(he - h - 1));
+            const uint8_t *p = (he < end) ? he + 1 : end;
+            r.seq_off = (size_t)(p - f.p);
+            r.end_off = (size_t)(end - f.p);
+            r.full_len = 0;
+            r.nul_at = UINT64_MAX;
+            while (p < end) {
+                const uint8_t *e = find_eol_py(p, end);
+                const uint8_t *a = p, *b = e;
+                strip_py(a, b);
+                r.full_len += (uint64_t)(b - a);
+                p = (e < end) ? e + 1 : end;
+            }
+            recs[i] = r;
+        }
+    });
+    return true;
+}
+
+bool analyse_records(const FileView &f, const std::vector<size_t> &hdrs, size_t tail_end, bool want_nul, RawVec<RecInfo> &recs) {
+    recs.n = 0;
+    if (hdrs.size() && !recs.grow(hdrs.size())) return false;
+    parallel_for(hdrs.size(), 256, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const uint8_t *h = f.p + hdrs[i];
+            const uint8_t *end = f.p + ((i + 1 < hdrs.size()) ? hdrs[i + 1] : tail_end);
             const uint8_t *he = find_nl(h, end);
             RecInfo r;
             r.predicted = header_has_predicted(h, (size_t)(he - h));
@@ -377,6 +474,18 @@ void pack_piece(const Piece &pc, uint64_t dst, uint32_t *bases, uint32_t *valid)
     uint64_t left = pc.take;
     if (!pc.lines) {
         sp.push(pc.src, (size_t)left);
+    } else if (pc.py) {
+        const uint8_t *p = pc.src;
+        while (p < pc.end && left) {
+            const uint8_t *e = find_eol_py(p, pc.end);
+            const uint8_t *a = p, *b = e;
+            strip_py(a, b);
+            size_t ln = (size_t)(b - a);
+            if (ln > left) ln = (size_t)left;
+            sp.push(a, ln);
+            left -= ln;
+            p = (e < pc.end) ? e + 1 : pc.end;
+        }
     } else {
         const uint8_t *p = pc.src;
         while (p < pc.end && left) {
@@ -478,11 +587,15 @@ void free_words(void *p, bool pinned) {
 
 extern "C" {
 
-int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int shard, int n_shards,
-                       kmers_store **out) {
+}  // extern "C"
+
+namespace {
+
+// by_bytes: the shard is a byte range of the files laid end to end (only its records are looked at; numbering is local)
+int ingest(int n_files, const char *fnames[], int mode, int L, int shard, int n_shards, bool by_bytes, kmers_store **out) {
     if (!out) return KMERS_ERR_BAD_ARG;
     *out = nullptr;
-    if (n_files < 0 || (n_files > 0 && !fnames) || mode < KMERS_MODE_X || mode > KMERS_MODE_Y_FASTQ || n_shards < 1 ||
+    if (n_files < 0 || (n_files > 0 && !fnames) || mode < KMERS_MODE_X || mode > KMERS_MODE_FASTA_PY || n_shards < 1 ||
         shard < 0 || shard >= n_shards)
         return KMERS_ERR_BAD_ARG;
 
@@ -503,6 +616,8 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
     const bool fastq = (mode == KMERS_MODE_Y_FASTQ);
     const bool cat = (mode == KMERS_MODE_X_CAT);
     const bool xmode = (mode == KMERS_MODE_X || cat);
+    const bool py = (mode == KMERS_MODE_FASTA_PY);
+    if (by_bytes && (fastq || cat)) return KMERS_ERR_BAD_ARG;      // one record per file: shard those by records
     const bool l_skips_all = xmode && L < 0;  // unsigned comparison in the reference
 
     // Everything that must outlive parsing: the mapped files and the inflated FASTQ sequences.
@@ -523,9 +638,22 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
     } else {
         std::vector<size_t> hdrs;
         RawVec<RecInfo> recs;
+        // by_bytes: the files laid end to end, this shard's range of that
+        std::vector<uint64_t> file_base((size_t)n_files + 1, 0);
+        if (by_bytes) {
+            for (int f = 0; f < n_files; ++f) {
+                struct stat sb;
+                if (stat(fnames[f], &sb) != 0 || !S_ISREG(sb.st_mode)) return KMERS_ERR_OPEN;
+                file_base[f + 1] = file_base[f] + (uint64_t)sb.st_size;
+            }
+        }
+        const unsigned __int128 bytes_total = file_base[n_files];
+        const uint64_t want_lo = by_bytes ? (uint64_t)(bytes_total * (unsigned)shard / (unsigned)n_shards) : 0;
+        const uint64_t want_hi = by_bytes ? (uint64_t)(bytes_total * (unsigned)(shard + 1) / (unsigned)n_shards) : UINT64_MAX;
         for (int f = 0; f < n_files; ++f) {
             files[f].reset(new FileView());
             FileView &fv = *files[f];
+            if (by_bytes && (file_base[f] >= want_hi || file_base[f + 1] <= want_lo)) continue;   // not this shard's: not mapped
             if (!fv.open(fnames[f])) {
                 if (cat) {  // reference src/libkmers.cpp:402-403: the job just returns, the column stays empty
                     if (!rec_len.push(0)) return KMERS_ERR_NOMEM;
@@ -534,9 +662,22 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
                 return KMERS_ERR_OPEN;  // reference src/libkmers.cpp:356-357, 440-441
             }
             if (getenv("KMERS_VERBOSE")) printf("processing %s\n", fnames[f]);
-            find_headers(fv, hdrs);
+            // this shard's bytes of the file: headers inside [lo, hi) are its records
+            const uint64_t fbase = file_base[f];
+            const size_t lo = (size_t)(want_lo > fbase ? want_lo - fbase : 0);
+            const size_t hi = (size_t)std::min<uint64_t>(fv.n, want_hi > fbase ? want_hi - fbase : 0);
+            const size_t tail_end = (hi >= fv.n) ? fv.n : next_header(fv, hi, py);
+            if (py) {
+                if (!find_headers_py(fv, lo, hi, hdrs)) {
+                    fprintf(stderr, "libkmers: %s holds bytes >= 0x80; the kmerexpr/fasta.py rules are restated for ASCII files only\n", fnames[f]);
+                    return KMERS_ERR_BAD_ARG;
+                }
+            } else {
+                find_headers(fv, lo, hi, hdrs);
+            }
             lap("find headers");
-            if (!analyse_records(fv, hdrs, xmode, recs)) return KMERS_ERR_NOMEM;
+            if (!(py ? analyse_records_py(fv, hdrs, tail_end, recs) : analyse_records(fv, hdrs, tail_end, xmode, recs)))
+                return KMERS_ERR_NOMEM;
             lap("analyse records");
             if (cat) {
                 uint64_t full = 0, nul = UINT64_MAX;
@@ -561,6 +702,7 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
                     const RecInfo &r = recs[i];
                     if (r.predicted) return 0;
                     if (xmode && (l_skips_all || r.full_len < (uint64_t)L)) return 0;
+                    if (py && L > 0 && r.full_len < (uint64_t)L) return 0;   // len(seq) >= L, signed (simulate_reads.py:88)
                     return 1;
                 };
                 std::unique_ptr<uint64_t[]> slot(new (std::nothrow) uint64_t[recs.size() + 1]);
@@ -577,7 +719,7 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
                         const uint64_t len = xmode ? std::min(r.full_len, r.nul_at) : r.full_len;
                         const uint64_t k = slot[i];
                         rl[k] = len;
-                        pc[k] = Piece{fv.p + r.seq_off, fv.p + r.end_off, rec0 + k, 0, len, true};
+                        pc[k] = Piece{fv.p + r.seq_off, fv.p + r.end_off, rec0 + k, 0, len, true, py};
                     }
                 });
             }
@@ -592,7 +734,7 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
     const uint64_t pos_total = parallel_prefix((size_t)n_total, gstart.get(), [&](size_t r) { return rec_len[r] + 1; });
     gstart[n_total] = pos_total;
     uint64_t r_lo = 0, r_hi = n_total;
-    if (n_shards > 1) {
+    if (n_shards > 1 && !by_bytes) {
         // record r belongs to shard floor(start_pos(r) * n_shards / pos_total)
         auto bound = [&](int s) -> uint64_t {  // first record of shard s
             if (s <= 0) return 0;
@@ -668,6 +810,23 @@ int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int s
     lap("pack");
     *out = st.release();
     return KMERS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kmers_store_ingest(int n_files, const char *fnames[], int mode, int L, int shard, int n_shards, kmers_store **out) {
+    return ingest(n_files, fnames, mode, L, shard, n_shards, false, out);
+}
+
+int kmers_store_ingest_bytes(int n_files, const char *fnames[], int mode, int L, int shard, int n_shards, kmers_store **out) {
+    return ingest(n_files, fnames, mode, L, shard, n_shards, true, out);
+}
+
+void kmers_store_set_numbering(kmers_store *s, uint64_t first_rec, uint64_t n_rec_total) {
+    s->first_rec = first_rec;
+    s->n_rec_total = n_rec_total;
 }
 
 void kmers_store_free(kmers_store *s) {

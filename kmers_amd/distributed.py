@@ -21,6 +21,32 @@ from . import _lib
 from .store import MODE_X, MODE_X_CAT, MODE_Y_FASTA, MODE_Y_FASTQ, Store
 
 
+def ingest_sharded(files, mode, L=0):
+    """This rank's shard of the records of `files`, with no rank parsing the whole input: rank r scans only its byte range
+    for headers (kmers_store_ingest_bytes), and one all-gather of the per-range record counts gives every shard its
+    first global record number.  The two one-record-per-file modes are sharded by records as before."""
+    import torch
+    dist = _dist()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if mode in (MODE_X_CAT, MODE_Y_FASTQ):
+        return Store(files, mode, L=L, shard=rank, n_shards=world)
+    st, err = None, 0
+    try:
+        st = Store(files, mode, L=L, shard=rank, n_shards=world, by_bytes=True)
+    except Exception as e:                       # every rank must reach the collective
+        err = e
+    mine = torch.tensor([st.n_rec if st is not None else -1], dtype=torch.int64)
+    if dist.get_backend() != "gloo":
+        mine = mine.cuda()
+    counts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(counts, mine)
+    counts = [int(c.item()) for c in counts]
+    if err or min(counts) < 0:
+        raise err or RuntimeError("kmers_store_ingest_bytes failed on rank %d" % counts.index(min(counts)))
+    st.set_numbering(sum(counts[:rank]), sum(counts))
+    return st
+
+
 def merge_csr_parts(parts, n_rows):
     """parts: list of (data f32[nnz_g], row_ind u64[n_rows+1], col_ind u64[nnz_g]) with ascending disjoint column
     ranges.  Returns (data, row_ind, col_ind) of the interleaved matrix."""
@@ -57,7 +83,7 @@ def count_y_sharded(files, K, fastq=False, device=None, count_fn=None):
     import torch
     dist = _dist()
     rank, world = dist.get_rank(), dist.get_world_size()
-    st = Store(files, MODE_Y_FASTQ if fastq else MODE_Y_FASTA, shard=rank, n_shards=world)
+    st = ingest_sharded(files, MODE_Y_FASTQ if fastq else MODE_Y_FASTA)
     if count_fn is None:
         counts = st.to_device(device or "cuda").count_y(K)
     else:
@@ -166,7 +192,7 @@ def build_x_sharded(files, K, L=0, concatenate_subseq=False, device=None, build_
     import torch
     dist = _dist()
     rank, world = dist.get_rank(), dist.get_world_size()
-    st = Store(files, MODE_X_CAT if concatenate_subseq else MODE_X, L=L, shard=rank, n_shards=world)
+    st = ingest_sharded(files, MODE_X_CAT if concatenate_subseq else MODE_X, L=L)
     M = 4 ** K
     if build_fn is None:
         ds = st.to_device(device or "cuda")
@@ -203,8 +229,8 @@ class ShardedModel:
         dist = _dist()
         rank, world = dist.get_rank(), dist.get_world_size()
         self.K = K
-        xs = Store(iso_files, MODE_X, L=L, shard=rank, n_shards=world)
-        ys = Store(reads_files, MODE_Y_FASTQ if fastq else MODE_Y_FASTA, shard=rank, n_shards=world)
+        xs = ingest_sharded(iso_files, MODE_X, L=L)
+        ys = ingest_sharded(reads_files, MODE_Y_FASTQ if fastq else MODE_Y_FASTA)
         self.T, self.first_col, self.n_local = xs.n_rec_total, xs.first_rec, xs.n_rec
         if make_model is None:
             dev = torch.device(device or "cuda")

@@ -5,14 +5,20 @@ Every random choice is the reference's, bit for bit: the same legacy numpy calls
 (np.random.seed(42), np.random.dirichlet, :55,:96) and the isoform of every read (np.random.choice(T, N, p), :105), and
 the same MT19937 stream continued for the per-read starts (np.random.choice(len - L + 1), :116, replayed in C by
 kmers_sim_starts instead of N Python-level calls).  Only the copying of the L bases of each read runs on the GPU
-(kmers_hip_simulate_reads).  The isoform list is the reference's: non-PREDICTED records of at least L bases, which is
-also the column rule of fasta_to_kmers_csr (a Store in MODE_X with the same L)."""
+(kmers_hip_simulate_reads).  The isoform list is the reference's: the records kmerexpr/fasta.py:19-46 yields (python
+text-mode lines, strip() on both sides, nothing before the first '>' line), filtered as simulate_reads.py:86-90 does
+(no "PREDICTED" in the header, at least L characters) -- a Store in MODE_FASTA_PY with the same L.  On a well-formed
+FASTA ('\n' line ends, no blanks, first byte '>') that is also the column list of fasta_to_kmers_csr (MODE_X); on
+anything else the two readers of the reference differ, and each of them is followed where the reference uses it
+(tests/test_simreads_cpu.py, tests/test_simreads_gpu.py: CRLF, inner blanks, text before the first header).
+Not restated: a read whose first character is '>' (possible only when a sequence line holds one) starts a new record
+when the reference's reads file is parsed back; here it stays part of the read."""
 import ctypes as C
 
 import numpy as np
 
 from . import _lib
-from .store import MODE_X, DeviceStore, Store
+from .store import MODE_FASTA_PY, DeviceStore, Store
 
 
 def length_adjustment(psi, lengths):
@@ -63,7 +69,7 @@ def simulate_reads_device(N, L, alpha, ISO_FILE, device="cuda", shard=0, n_shard
     [shard N / n_shards, (shard + 1) N / n_shards); the histograms are then summed with one all-reduce."""
     import torch
     lib = _lib.handle()
-    st = Store(ISO_FILE, MODE_X, L=L)
+    st = Store(ISO_FILE, MODE_FASTA_PY, L=L)
     rs = st.rec_start.astype(np.int64)
     info = sample_reads(np.diff(rs) - 1, N, L, alpha)
     ds = st.to_device(device)

@@ -10,18 +10,24 @@ import numpy as np
 
 from . import _lib
 
-MODE_X, MODE_X_CAT, MODE_Y_FASTA, MODE_Y_FASTQ = 0, 1, 2, 3
+MODE_X, MODE_X_CAT, MODE_Y_FASTA, MODE_Y_FASTQ, MODE_FASTA_PY = 0, 1, 2, 3, 4
 
 
 class Store:
-    def __init__(self, files, mode, L=0, shard=0, n_shards=1):
+    def __init__(self, files, mode, L=0, shard=0, n_shards=1, by_bytes=False):
+        """by_bytes: the shard is a byte range of the files and only that range is parsed (kmers_store_ingest_bytes);
+        record numbers are local until set_numbering() -- kmers_amd.distributed.ingest_sharded does both."""
         files = [files] if isinstance(files, str) else list(files)
         self._lib = _lib.handle()
         h = C.c_void_p()
-        rc = self._lib.kmers_store_ingest(len(files), _lib.cfiles(files), mode, L, shard, n_shards, C.byref(h))
-        _lib.check(rc, "kmers_store_ingest")
+        fn = self._lib.kmers_store_ingest_bytes if by_bytes else self._lib.kmers_store_ingest
+        rc = fn(len(files), _lib.cfiles(files), mode, L, shard, n_shards, C.byref(h))
+        _lib.check(rc, "kmers_store_ingest_bytes" if by_bytes else "kmers_store_ingest")
         self._h = h
         self.mode = mode
+
+    def set_numbering(self, first_rec, n_rec_total):
+        self._lib.kmers_store_set_numbering(self._h, first_rec, n_rec_total)
 
     def close(self):
         if getattr(self, "_h", None):

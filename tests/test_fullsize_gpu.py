@@ -192,7 +192,23 @@ def test_config4_full_size_build_count_fit(full):
     assert abs(val - want_val) < 1e-5 * abs(want_val)
     g_dev = torch.as_tensor(grad, device=dev).double()
     assert float((g_dev - want_grad).abs().max()) < 2e-4 * float(want_grad.abs().max())
-    del r, c, d, xt, w
+    # (2b) the float64 checker itself against oracle/logp_grad.py on a sample of 10^5 masked rows (the oracle's scipy
+    # statement of kmerexpr/utils.py:46-73 finishes in seconds at that size): same val and gradient contributions
+    import scipy.sparse as sp
+    from oracle.logp_grad import logp_grad_ref
+    rows_m = mask.nonzero().squeeze(1)
+    pick = rows_m[torch.randperm(rows_m.numel(), generator=g)[:100_000].to(dev)].sort().values
+    sel = torch.zeros(M, dtype=torch.bool, device=dev)
+    sel[pick] = True
+    new_id = torch.cumsum(sel, 0) - 1
+    k2 = sel[r]
+    xs_ = sp.csr_matrix((d[k2].cpu().numpy(), (new_id[r[k2]].cpu().numpy(), c[k2].cpu().numpy())), shape=(pick.numel(), T))
+    o_val, o_grad, o_xt = logp_grad_ref(theta.cpu().numpy(), 1.0, xs_, ynorm[pick].cpu().numpy(), np.ones(T))
+    assert np.allclose(o_xt, xt[pick].cpu().numpy(), rtol=2e-7, atol=0)          # the oracle rounds xtheta to float32
+    assert abs(o_val - float((ynorm[pick] * torch.log(xt[pick])).sum())) < 1e-6 * abs(o_val)
+    t_grad = torch.zeros(T, dtype=torch.float64, device=dev).index_add_(0, c[k2], d[k2] * w[r[k2]]).cpu().numpy()
+    assert np.abs(o_grad - t_grad).max() < 1e-6 * np.abs(t_grad).max()
+    del r, c, d, xt, w, k2, sel, new_id
     # (3) exponentiated-gradient steps (kmerexpr/exp_grad_solver.py:60-64, default step) raise the likelihood
     theta = torch.full((T,), 1.0 / T, dtype=torch.float32, device=dev)
     v0, g0 = dm.logp_grad(theta)

@@ -74,6 +74,42 @@ def test_store_shards_partition_records(n_shards):
     assert max(sizes) - min(sizes) <= max(len(s) for s in whole) + 1   # balanced by positions
 
 
+@pytest.mark.parametrize("n_shards", [2, 3, 7, 64])
+def test_byte_range_shards_are_the_whole_in_order(tmp_path, n_shards):
+    """kmers_store_ingest_bytes: every rank parses only its byte range; the shards in order are the whole record list
+    under all three record rules, with headers on and next to the range boundaries, several files, an empty file, a
+    file whose empty first line ends it (C++ rules) and one that starts with text (fasta.py rules)."""
+    from kmers_amd.store import MODE_FASTA_PY
+    from tests.test_simreads_cpu import awkward_fasta
+    e1 = tmp_path / "empty.fsa"
+    e1.write_bytes(b"")
+    e2 = tmp_path / "blankfirst.fsa"
+    e2.write_bytes(b"\n>a\nACGTACGT\n>b\nACGT\n")
+    tiny = tmp_path / "tiny.fsa"
+    tiny.write_bytes(b">t1\nAC\n>t2\n\n>t3 PREDICTED\nACGT\n>t4\nACGTACGTAC")
+    files = [os.path.join(kmtest.INP, "syn_small.fsa"), str(e1), awkward_fasta(str(tmp_path / "awk.fsa")), str(e2),
+             os.path.join(kmtest.INP, "ref_test4.fsa"), str(tiny)]
+    for mode, L in ((MODE_X, 0), (MODE_X, 9), (MODE_Y_FASTA, 0), (MODE_FASTA_PY, 0), (MODE_FASTA_PY, 100)):
+        whole = Store(files, mode, L=L).sequences()
+        got = []
+        for s in range(n_shards):
+            st = Store(files, mode, L=L, shard=s, n_shards=n_shards, by_bytes=True)
+            assert st.first_rec == 0 and st.n_rec_total == st.n_rec          # local until set_numbering
+            st.set_numbering(len(got), len(whole))
+            assert st.first_rec == len(got) and st.n_rec_total == len(whole)
+            got += st.sequences()
+        assert got == whole, (mode, L)
+    # every split point of a small file, including the ones on a header and on the byte before it
+    size = os.path.getsize(str(tiny))
+    whole = Store([str(tiny)], MODE_Y_FASTA).sequences()
+    for n in range(2, size + 2):
+        assert sum((Store([str(tiny)], MODE_Y_FASTA, shard=s, n_shards=n, by_bytes=True).sequences() for s in range(n)), []) == whole
+    with pytest.raises(RuntimeError):
+        Store([str(tiny)], MODE_X_CAT, shard=0, n_shards=2, by_bytes=True)    # one record per file: sharded by records
+    with pytest.raises(RuntimeError, match="Failed to open FASTA"):
+        Store([str(tmp_path / "nope.fsa")], MODE_X, shard=0, n_shards=2, by_bytes=True)
+
+
 def test_threads_do_not_change_the_store(monkeypatch):
     files = [os.path.join(kmtest.INP, "syn_small.fsa")]
     monkeypatch.setenv("KMER_NUM_THREADS", "1")

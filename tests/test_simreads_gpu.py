@@ -54,6 +54,25 @@ def test_simulated_store_equals_reference_reads(oracle, iso, tmp_path, N, L, alp
         assert rc == 0 and np.array_equal(ds.count_y(K).cpu().numpy(), y), K
 
 
+def test_reads_from_a_file_the_two_reference_readers_see_differently(oracle, tmp_path):
+    """CRLF / lone-CR line ends, blanks python strips, text before the first header, a NUL: the isoforms are those of
+    kmerexpr/fasta.py (the simulator's reader), the reads file is then counted by the C++ reader's rules -- as in the
+    reference, where simulate_reads writes the file and fasta_count_kmers reads it."""
+    from kmers_amd.simulate_reads import simulate_reads_device
+    from tests.test_simreads_cpu import awkward_fasta
+    p = awkward_fasta(str(tmp_path / "awk.fsa"), seed=9)
+    for N, L in ((3000, 100), (2000, 31)):
+        reads = str(tmp_path / f"reads{L}.fsa")
+        want = orc.simulate_reads(N, L, 0.3, reads, p)
+        ds, info = simulate_reads_device(N, L, 0.3, p)
+        assert np.array_equal(info["iso_sampled"], want["iso_sampled"])
+        assert np.array_equal(info["starts"].astype(np.int64), want["starts"])
+        assert np.array_equal(info["lengths"], want["lengths"])
+        for K in (5, 12):
+            rc, y = oracle.y([reads], K)
+            assert rc == 0 and np.array_equal(ds.count_y(K).cpu().numpy(), y), (L, K)
+
+
 def test_bad_isoform_or_start_is_rejected(iso):
     import torch
     from kmers_amd import _lib
