@@ -413,55 +413,121 @@ __global__ __launch_bounds__(YL_NT) void k_count_y_lds(BasesArgs a, int32_t *cou
 // ------------------------------------------------------------------------------------------------------
 
 // Pass 0 histogram, straight from the packed bases.  Also accumulates the number of valid windows per record
-// (the reference's total_count, src/libkmers.cpp:220-227) with one atomic per (wave round, record).
-__global__ __launch_bounds__(NT) void k_hist_bases(BasesArgs a, uint32_t *tilehist, uint32_t n_tiles, uint32_t *rec_total) {
-    __shared__ TileLds L;
-    __shared__ uint32_t stmp[NW];
-    __shared__ uint32_t h[NW][RADIX];
-    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
-    const uint32_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
-    const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
-    if (t0 >= t1) return;
-    TilePf pf = tile_fetch<true>(a, t0);
-    for (uint32_t tile = t0; tile < t1; ++tile) {
-        for (uint32_t i = tid; i < NW * RADIX; i += NT) (&h[0][0])[i] = 0;
-        tile_commit<true>(L, pf, stmp);
-        if (tile + 1 < t1) pf = tile_fetch<true>(a, tile + 1);
-        const RecLanes rl = rec_lanes_load(L, w, lane);
-#pragma unroll 2
-        for (int j = 0; j < IPT; ++j) {
-            const uint32_t o = w * WCHUNK + j * 64 + lane;
-            uint32_t key;
-            const bool ok = window_at(L, o, a.K, key);
-            if (ok) atomicAdd(&h[w][key & 255u], 1u);
-            // valid windows per record: lanes are position-ordered, so records form contiguous lane segments
-            const u64 okm = __ballot(ok);
-            if (okm) {
-                u64 f;
-                const uint32_t rec = rec_lanes_at(rl, j, lane, f);
-                if ((f >> 1) == 0) {  // one record for the whole round (it may start at lane 0)
-                    if (lane == 0) atomicAdd(&rec_total[rec], (uint32_t)__popcll(okm));
-                } else {
-                    const bool first = (lane == 0) || ((f >> lane) & 1ull);
-                    const u64 fm = f | 1ull;  // segment starts
-                    if (first) {
-                        const u64 above = (lane == 63) ? 0ull : (fm & ~((2ull << lane) - 1ull));
-                        const uint32_t endl = above ? (uint32_t)__ffsll((long long)above) - 1u : 64u;
-                        const u64 seg = ((endl == 64) ? ~0ull : ((1ull << endl) - 1ull)) & ~lanes_below(lane);
-                        const uint32_t cnt = (uint32_t)__popcll(okm & seg);
-                        if (cnt) atomicAdd(&rec_total[rec], cnt);
-                    }
+// (the reference's total_count, src/libkmers.cpp:220-227).
+//
+// One WAVE per tile and no workgroup barrier: a lane takes one packed word (the 16 windows that start in it, shifted
+// out of registers as in the y kernels -- a histogram does not care about the order), the wave has a 256-bin table of
+// its own in LDS (the LDS executes one wave's operations in order), and after the tile's 8 groups of 64 words each lane
+// moves 4 bins to the tile's histogram row.  rec_total: the record starts are bits of rec_flags; words without a start
+// (all but ~1 in 150 on a transcriptome) add their windows to a wave-wide sum that is carried in a scalar from group to
+// group and flushed with ONE atomic when a record ends or the tile does; words with starts split their windows between
+// the records around them with one segmented sum over the wave's lanes.
+constexpr int HB_NT = 256, HB_NW = HB_NT / 64;
+constexpr int HB_GROUPS = TILE / (64 * 16);  // groups of 64 words per tile
+
+// bit j of the result = bits j .. j + K - 1 of v are all set (1 <= K <= 16); only bits 0..15 are meaningful for a 32-bit v
+__device__ __forceinline__ uint32_t runs_of(uint32_t v, int K) {
+    uint32_t r = v;
+    int s = 1;
+    while (2 * s <= K) {  // K is wave-uniform: scalar loop, at most 4 rounds
+        r &= r >> s;
+        s *= 2;
+    }
+    return r & (r >> (K - s));
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d);
+        if (lane >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(HB_NT) void k_hist_bases(BasesArgs a, uint32_t *tilehist, uint32_t n_tiles, uint32_t *rec_total) {
+    __shared__ uint32_t hs[HB_NW][RADIX];
+    const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
+    uint32_t *const h = hs[w];
+    const uint32_t n_waves = gridDim.x * HB_NW, wave = blockIdx.x * HB_NW + w;
+    const int K = a.K;
+    const uint32_t ksh = 32u - 2u * (uint32_t)K;
+#pragma unroll
+    for (int i = 0; i < RADIX / 64; ++i) h[lane + 64 * i] = 0u;
+    for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+        uint32_t rec_base = __builtin_amdgcn_readfirstlane(a.tile_cb[tile]);  // record starts strictly before the group
+        uint32_t carry = 0;  // valid windows of record rec_base - 1 seen in this tile and not yet added (wave-uniform)
+        const uint64_t g0 = (uint64_t)tile * (TILE / 16) + lane;
+        WordWindows nx = word_fetch(a, g0);
+        uint32_t nfw = ((g0 >> 1) < a.valid_words) ? a.rec_flags[g0 >> 1] : 0u;
+        for (int i = 0; i < HB_GROUPS; ++i) {
+            const uint64_t g = g0 + (uint64_t)i * 64;
+            const WordWindows x = nx;
+            const uint32_t fl = (g & 1) ? (nfw >> 16) : (nfw & 0xFFFFu);  // record starts among positions 16 g .. 16 g + 15
+            if (i + 1 < HB_GROUPS) {
+                nx = word_fetch(a, g + 64);
+                nfw = (((g + 64) >> 1) < a.valid_words) ? a.rec_flags[(g + 64) >> 1] : 0u;
+            }
+            const uint32_t okm = runs_of(x.v, K) & 0xFFFFu;  // bit j: window j of the word is a k-mer
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t top = j ? __builtin_amdgcn_alignbit(x.b0, x.b1, 32u - 2u * (uint32_t)j) : x.b0;
+                if ((okm >> j) & 1u) atomicAdd(&h[(top >> ksh) & 255u], 1u);
+            }
+            // ---- valid windows per record
+            const uint32_t call = (uint32_t)__popc(okm);
+            const u64 hb = __ballot(fl != 0u);
+            if (hb == 0ull) {  // no record starts in these 1024 positions
+                uint32_t t = call;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+                carry += __builtin_amdgcn_readfirstlane(t);
+                continue;
+            }
+            // flagged words: windows before the first start (A) belong to the record that is open, windows from the
+            // last start on (B) to the record it opens, windows between two starts of one word are added at once
+            const uint32_t nfl = (uint32_t)__popc(fl);
+            uint32_t cntA = 0, cntB = 0;
+            if (fl) {
+                cntA = (uint32_t)__popc(okm & ((fl & (0u - fl)) - 1u));
+                cntB = (uint32_t)__popc(okm & ~((1u << (31 - __clz(fl))) - 1u));
+            }
+            const uint32_t sc = wave_incl_scan((fl ? 0u : call) | (nfl << 16), lane);
+            const uint32_t p_incl = sc & 0xFFFFu, f_incl = sc >> 16;
+            if (nfl >= 2u) {  // records that start and end inside one word
+                uint32_t f = fl, rec = rec_base + f_incl - nfl;
+                while (f & (f - 1u)) {
+                    const uint32_t lo = (uint32_t)__ffs((int)f) - 1u;
+                    f &= f - 1u;
+                    const uint32_t hi = (uint32_t)__ffs((int)f) - 1u;
+                    const uint32_t c = (uint32_t)__popc(okm & ((1u << hi) - (1u << lo)));
+                    if (c) atomicAdd(&rec_total[rec], c);
+                    ++rec;
                 }
             }
+            const u64 above = (lane == 63u) ? 0ull : (hb & ~((2ull << lane) - 1ull));
+            const uint32_t e = above ? (uint32_t)__ffsll((long long)above) - 1u : 64u;  // next flagged lane
+            const uint32_t p_em1 = __shfl(p_incl, (int)((e - 1u) & 63u)), a_e = __shfl(cntA, (int)(e & 63u));
+            const uint32_t seg = cntB + (p_em1 - p_incl) + (e < 64u ? a_e : 0u);  // (flagged lanes) the record opened here
+            if (fl && e < 64u && seg) atomicAdd(&rec_total[rec_base + f_incl - 1u], seg);
+            // head: the open record up to the first flagged lane
+            const uint32_t e0 = __builtin_amdgcn_readfirstlane((uint32_t)__ffsll((long long)hb) - 1u);
+            uint32_t head = carry + (uint32_t)__builtin_amdgcn_readlane((int)cntA, (int)e0);
+            if (e0) head += (uint32_t)__builtin_amdgcn_readlane((int)p_incl, (int)(e0 - 1u));
+            if (head && lane == 0u) atomicAdd(&rec_total[rec_base - 1u], head);  // (head > 0 implies a record is open)
+            const uint32_t last = __builtin_amdgcn_readfirstlane(63u - (uint32_t)__clzll((long long)hb));
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)seg, (int)last);
+            rec_base += (uint32_t)__builtin_amdgcn_readlane((int)f_incl, 63);
         }
-        lds_sync();
-        if (tid < RADIX) {
-            uint32_t s = 0;
+        if (carry && lane == 0u) atomicAdd(&rec_total[rec_base - 1u], carry);
+        // the wave's table -> the tile's row; zeroed for the next tile
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < NW; ++i) s += h[i][tid];
-            tilehist[(uint64_t)tile * RADIX + tid] = s;
+        for (int i = 0; i < RADIX / 64; ++i) {
+            const uint32_t v = h[lane + 64 * i];
+            tilehist[(uint64_t)tile * RADIX + lane + 64 * i] = v;
+            h[lane + 64 * i] = 0u;
         }
-        lds_sync();
     }
 }
 
@@ -2745,7 +2811,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     const uint32_t *c_hist = hist, *c_E = &scal[0];
 
     // pass 0: packed bases -> instances partitioned by the lowest digit
-    hipLaunchKernelGGL(k_hist_bases, hgrid, block, 0, s, a, hist, l.n_tiles, total);
+    hipLaunchKernelGGL(k_hist_bases, dim3(l.n_tiles < 4096u ? (l.n_tiles + HB_NW - 1) / HB_NW : 1024u), dim3(HB_NT), 0, s, a, hist, l.n_tiles, total);
     pt.mark("k_hist_bases");
     if (int rc = scan_tilehist(hist, l.n_tiles, bsum, &scal[0], s)) return rc;
     pt.mark("k_scan");
