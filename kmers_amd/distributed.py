@@ -160,12 +160,32 @@ def concat_x_shards(data, col_ind, row_ind, nnz, n_rows, gloo=False):
     # mapping rank 0 returns keeps the pages until its arrays go)
     shapes = ((max(total, 1), np.float32), (max(total, 1), np.uint64), (n_rows + 1, np.uint64))
     base = [None]
-    if rank == 0:
-        base[0] = os.path.join(_SHM_DIR, "kmers_x_%d_%d" % (os.getpid(), next(_shm_serial)))
-        for i, (n, dt) in enumerate(shapes):
-            with open(base[0] + ".%d" % i, "wb") as f:
-                f.truncate(n * np.dtype(dt).itemsize)
+    if rank == 0:       # a directory with room for the whole matrix; the space is reserved now (posix_fallocate), so a full
+        need = sum(n * np.dtype(dt).itemsize for n, dt in shapes)      # tmpfs shows as an error here, not as SIGBUS later
+        for d in (_SHM_DIR, tempfile.gettempdir()):
+            stem = os.path.join(d, "kmers_x_%d_%d" % (os.getpid(), next(_shm_serial)))
+            try:
+                fs = os.statvfs(d)
+                if fs.f_bavail * fs.f_frsize < need + (64 << 20):
+                    continue
+                for i, (n, dt) in enumerate(shapes):
+                    fd = os.open(stem + ".%d" % i, os.O_CREAT | os.O_RDWR | os.O_EXCL, 0o600)
+                    try:
+                        os.posix_fallocate(fd, 0, n * np.dtype(dt).itemsize)
+                    finally:
+                        os.close(fd)
+                base[0] = stem
+                break
+            except OSError:
+                for i in range(3):
+                    try:
+                        os.unlink(stem + ".%d" % i)
+                    except OSError:
+                        pass
     dist.broadcast_object_list(base, src=0)           # one short string
+    if base[0] is None:                               # (every rank raises: no collective is left half done)
+        raise RuntimeError("concat_x_shards: no room for the whole matrix (%d non-zeros) in %s or %s"
+                           % (total, _SHM_DIR, tempfile.gettempdir()))
     try:
         o_data, o_col, o_row = (np.memmap(base[0] + ".%d" % i, dtype=dt, mode="r+", shape=(n,))
                                 for i, (n, dt) in enumerate(shapes))
