@@ -199,18 +199,14 @@ int count_files(int n_files, const char *fnames[], int K, int *counts, int mode)
     return KMERS_OK;
 }
 
-int build_files(int n_files, const char *fnames[], int K, int L, int mode, float *data, uint64_t *row_ind, uint64_t *col_ind,
-                uint64_t max_size, uint64_t *nnz, int *n_cols) {
-    if (K < 1 || K > 16 || !row_ind || !nnz || !n_cols || n_files < 0 || (max_size && (!data || !col_ind)))
-        return KMERS_ERR_BAD_ARG;
-    StageClock clk;
-    StoreGuard g;
-    if (int rc = kmers_store_ingest(n_files, fnames, mode, L, 0, 1, &g.s)) return rc;
-    clk.lap("host ingest");
-    if (int rc = select_device()) return rc;
-    const kmers_store *st = g.s;
+constexpr uint64_t X_MAX_POS = 0xFFFF0000ull, X_MAX_REC = 0x7FFFFFFFull;  // one kmers_hip_build_x call (32-bit entry indices)
+
+// One store -> CSR in host arrays (data / col_ind hold min(max_size, windows) entries, row_ind 4^K + 1); columns are
+// numbered from the store's first record.
+int build_store(const kmers_store *st, int K, uint64_t max_size, float *data, uint64_t *row_ind, uint64_t *col_ind, uint64_t *nnz,
+                StageClock &clk) {
     const uint64_t n_pos = kmers_store_n_pos(st), n_rec = kmers_store_n_rec(st);
-    if (n_pos > 0xFFFF0000ull || n_rec > 0x7FFFFFFFull) return KMERS_ERR_TOO_LARGE;
+    if (n_pos > X_MAX_POS || n_rec > X_MAX_REC) return KMERS_ERR_TOO_LARGE;
     const uint64_t M = 1ull << (2 * K);
     const uint64_t windows = kmers_store_n_windows(st, K);   // upper bound on nnz
     const uint64_t cap = std::min<uint64_t>(max_size, windows);
@@ -226,8 +222,8 @@ int build_files(int n_files, const char *fnames[], int K, int L, int mode, float
     clk.lap("H2D + device buffers");
     uint64_t nz = 0;
     const int rc = kk::build_x(ds.bases.as<uint32_t>(), st->bases_words, ds.valid.as<uint32_t>(), st->valid_words,
-                               ds.rec_start.as<uint64_t>(), n_pos, n_rec, 0, K, d_data.as<float>(), d_col.as<uint64_t>(),
-                               d_row.as<uint64_t>(), cap, d_ws.p, ws_bytes, &nz, s);
+                               ds.rec_start.as<uint64_t>(), n_pos, n_rec, kmers_store_first_rec(st), K, d_data.as<float>(),
+                               d_col.as<uint64_t>(), d_row.as<uint64_t>(), cap, d_ws.p, ws_bytes, &nz, s);
     if (rc == KMERS_ERR_MAX_NZ && nz <= max_size) {
         fprintf(stderr, "libkmers: internal error: nnz %llu above the window count %llu\n", (unsigned long long)nz,
                 (unsigned long long)windows);
@@ -240,9 +236,88 @@ int build_files(int n_files, const char *fnames[], int K, int L, int mode, float
         if (int e = d2h_copy(col_ind, d_col.p, nz * 8, s)) return e;
         if (int e = d2h_copy(data, d_data.p, nz * 4, s)) return e;
     }
-    clk.lap("D2H into the caller's arrays");
+    clk.lap("D2H into the host arrays");
     *nnz = nz;
-    *n_cols = (int)kmers_store_n_rec_total(st);
+    return KMERS_OK;
+}
+
+struct HostCsr {  // one chunk's matrix while the others are built
+    float *data = nullptr;
+    uint64_t *col = nullptr, *row = nullptr;
+    uint64_t nnz = 0;
+    HostCsr() = default;
+    HostCsr(const HostCsr &) = delete;
+    HostCsr &operator=(const HostCsr &) = delete;
+    HostCsr(HostCsr &&o) noexcept : data(o.data), col(o.col), row(o.row), nnz(o.nnz) { o.data = nullptr, o.col = o.row = nullptr; }
+    ~HostCsr() {
+        free(data);
+        free(col);
+        free(row);
+    }
+};
+
+int build_files(int n_files, const char *fnames[], int K, int L, int mode, float *data, uint64_t *row_ind, uint64_t *col_ind,
+                uint64_t max_size, uint64_t *nnz, int *n_cols) {
+    if (K < 1 || K > 16 || !row_ind || !nnz || !n_cols || n_files < 0 || (max_size && (!data || !col_ind)))
+        return KMERS_ERR_BAD_ARG;
+    StageClock clk;
+    const uint64_t M = 1ull << (2 * K);
+    uint64_t n_pos, n_rec_total, n_ranges;
+    {
+        StoreGuard g;
+        if (int rc = kmers_store_ingest(n_files, fnames, mode, L, 0, 1, &g.s)) return rc;
+        clk.lap("host ingest");
+        if (int rc = select_device()) return rc;
+        n_pos = kmers_store_n_pos(g.s);
+        n_rec_total = kmers_store_n_rec_total(g.s);
+        // positions one device call takes; KMERS_X_CHUNK_POS lowers it (tests of the chunked route at small sizes)
+        uint64_t chunk_pos = X_MAX_POS;
+        if (const char *e = getenv("KMERS_X_CHUNK_POS")) {
+            const long long v = atoll(e);
+            if (v > 0 && (uint64_t)v < X_MAX_POS) chunk_pos = (uint64_t)v;
+        }
+        if (n_pos <= chunk_pos && n_rec_total <= X_MAX_REC) {
+            uint64_t nz = 0;
+            if (int rc = build_store(g.s, K, max_size, data, row_ind, col_ind, &nz, clk)) return rc;
+            *nnz = nz;
+            *n_cols = (int)n_rec_total;
+            return KMERS_OK;
+        }
+        n_pos = std::max<uint64_t>(n_pos, 1);
+        // more positions than one device call indexes: contiguous record ranges (the ingest's shards, balanced by
+        // positions), one matrix each, interleaved row by row at the end (columns ascend from range to range)
+        const uint64_t by_pos = (n_pos + chunk_pos - 1) / chunk_pos, by_rec = n_rec_total / X_MAX_REC + 1;
+        const uint64_t want = std::max(by_pos, by_rec);
+        if (want > 4096) return KMERS_ERR_TOO_LARGE;
+        n_ranges = want;
+    }
+    const int n_parts = (int)n_ranges;
+    std::vector<HostCsr> parts((size_t)n_parts);
+    uint64_t total = 0;
+    for (int p = 0; p < n_parts; ++p) {
+        StoreGuard g;
+        if (int rc = kmers_store_ingest(n_files, fnames, mode, L, p, n_parts, &g.s)) return rc;
+        const uint64_t windows = kmers_store_n_windows(g.s, K);
+        HostCsr &h = parts[(size_t)p];
+        h.data = (float *)malloc(std::max<uint64_t>(windows, 1) * 4);
+        h.col = (uint64_t *)malloc(std::max<uint64_t>(windows, 1) * 8);
+        h.row = (uint64_t *)malloc((M + 1) * 8);
+        if (!h.data || !h.col || !h.row) return KMERS_ERR_NOMEM;
+        if (int rc = build_store(g.s, K, windows, h.data, h.row, h.col, &h.nnz, clk)) return rc;  // (a single record above the cap: TOO_LARGE)
+        total += h.nnz;
+        if (h.nnz < windows) {  // give the slack back before the next range is built
+            if (void *q = realloc(h.data, std::max<uint64_t>(h.nnz, 1) * 4)) h.data = (float *)q;
+            if (void *q = realloc(h.col, std::max<uint64_t>(h.nnz, 1) * 8)) h.col = (uint64_t *)q;
+        }
+    }
+    *nnz = total;
+    *n_cols = (int)n_rec_total;
+    if (total > max_size) return KMERS_ERR_MAX_NZ;
+    std::vector<const float *> pd;
+    std::vector<const uint64_t *> pr, pc;
+    for (const HostCsr &h : parts) pd.push_back(h.data), pr.push_back(h.row), pc.push_back(h.col);
+    if (int rc = kmers_csr_merge(n_parts, M, pd.data(), pr.data(), pc.data(), data, row_ind, col_ind)) return rc;
+    clk.lap("interleave of the ranges");
     return KMERS_OK;
 }
 
@@ -258,7 +333,7 @@ int report(int rc, const char *call) {
         case KMERS_ERR_NO_DEVICE: why = "no usable HIP device (this library has no CPU fallback); outputs were not written"; break;
         case KMERS_ERR_HIP: why = "a HIP runtime call failed; outputs are incomplete"; break;
         case KMERS_ERR_BAD_ARG: why = "bad argument (K outside 1..16, a null pointer, a negative count, KMERS_DEVICE out of range)"; break;
-        case KMERS_ERR_TOO_LARGE: why = "input too large for one device call (more than 2^32-65536 positions)"; break;
+        case KMERS_ERR_TOO_LARGE: why = "input too large (one record, or one device-level call, of more than 2^32-65536 positions)"; break;
         case KMERS_ERR_WORKSPACE: why = "workspace too small"; break;
         case KMERS_ERR_NOMEM: why = "host allocation failed"; break;
     }

@@ -58,6 +58,20 @@ def test_x_wide_entries_for_small_k(product, oracle, syn, K, monkeypatch):
     kmtest.assert_x_equal(product.x([syn["iso"], syn["uni"]], K), oracle.x([syn["iso"], syn["uni"]], K))
 
 
+@pytest.mark.parametrize("K,L,cat", [(8, 0, False), (13, 900, False), (6, 0, True), (11, 2000, True)])
+def test_x_in_record_ranges_above_the_per_call_limit(product, oracle, syn, K, L, cat, monkeypatch):
+    """An input of more positions than one device call indexes (2^32 - 65536) is built in contiguous record ranges that
+    are interleaved row by row on the host.  KMERS_X_CHUNK_POS lowers the limit so that the route runs here: 4 M
+    positions in ranges of at most ~300,000 (14 of them), one file per column in the cat mode (2 ranges)."""
+    files = [syn["iso"], syn["uni"]]
+    want = oracle.x(files, K, L, cat)
+    monkeypatch.setenv("KMERS_X_CHUNK_POS", "2000000" if cat else "300000")
+    kmtest.assert_x_equal(product.x(files, K, L, cat), want)
+    nnz = want[1].shape[0]
+    assert product.x(files, K, L, cat, max_nz=nnz)[0] == 0
+    assert product.x(files, K, L, cat, max_nz=nnz - 1)[0] == -2
+
+
 @pytest.mark.parametrize("K,L,cat", [(8, 1500, False), (12, 0, True), (6, 2000, True), (14, 0, False)])
 def test_x_variants_vs_oracle(product, oracle, syn, K, L, cat):
     files = [syn["iso"], syn["uni"]]
