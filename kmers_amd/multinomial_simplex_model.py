@@ -1,9 +1,13 @@
 """`multinomial_simplex_model` with the reference's constructor and `logp_grad` (reference
 kmerexpr/multinomial_simplex_model.py:10-95, kmerexpr/utils.py:76-108), X and y resident in HBM.
 
-The reference's solvers (`fit` -> exp_grad_solver / mg, multinomial_simplex_model.py:117-146) only ever call
-`model.logp_grad(theta, nograd=...)` and the `initialize_iterates_*` helpers; they are host-side Python outside this
-library's scope and run unchanged on an instance of this class."""
+What is here: the constructor, `logp_grad(theta, nograd)`, `initialize_iterates_uniform`, and a `fit` that hands
+`self.logp_grad` to the reference's own solvers (exp_grad_solver / mg, imported from an installed `kmerexpr`: they are
+host-side Python outside this library's scope and only ever call `logp_grad`).  What is NOT here: the attributes
+`ymask / xnnz / ynnz / scratch` (X and y live in HBM, `self.device_model`), `initialize_iterates_Xy` and
+`initialize_iterates_lsq` (they need the host copies; `fit` says so when `model_parameters.init_iterates` asks for
+them).  The log term is accumulated in float64 where the reference's numba loop works on its float32 scratch:
+agreement to float32 rounding, not bit parity (tests/test_model_gpu.py states the tolerance)."""
 import numpy as np
 
 from .model import DeviceModel
@@ -55,3 +59,22 @@ class multinomial_simplex_model:
         """reference multinomial_simplex_model.py:97-101"""
         alpha = np.ones(self.T)
         return alpha / alpha.sum()
+
+    def fit(self, model_parameters, theta0=None, tol=1e-20, gtol=1e-20, n_iters=100, opt_method="mg"):
+        """The reference's dispatch (multinomial_simplex_model.py:117-146) onto its own solvers, which must be importable
+        (`kmerexpr.exp_grad_solver`, `kmerexpr.mg`); only the uniform start is available without the host copies."""
+        if theta0 is None:
+            init = getattr(model_parameters, "init_iterates", "uniform")
+            if init in ("lsq", "Xy"):
+                raise NotImplementedError("init_iterates=%r needs xnnz / ynnz on the host; pass theta0, or use the "
+                                          "uniform start" % init)
+            theta0 = self.initialize_iterates_uniform()
+        try:  # the reference's imports (multinomial_simplex_model.py:3-4)
+            from kmerexpr.exp_grad_solver import exp_grad_solver
+            from kmerexpr.mg import mg
+        except ImportError as e:
+            raise ImportError("fit() runs the reference's solvers: install kmerexpr, or call a solver of your own with "
+                              "model.logp_grad") from e
+        if opt_method == "mg":
+            return mg(self.logp_grad, theta0, tol=tol, max_iter=n_iters)
+        return exp_grad_solver(self.logp_grad, theta0, lrs=model_parameters.lrs, tol=tol, gtol=gtol, n_iters=n_iters)
