@@ -141,17 +141,27 @@ __global__ void k_regions(const uint32_t *tilebase, uint32_t n_tiles, const uint
 // the waves of a workgroup, so waiting for this wave's LDS operations before the barrier is all that is needed.
 __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Inclusive scan over the 64 lanes of a wave in registers: four row_shr steps inside each row of 16 lanes, then the
+// row totals cross with row_bcast:15 / row_bcast:31 (DPP: a few cycles per step; the six ds_bpermute steps of a
+// __shfl_up scan are six dependent LDS round trips, ~1 us per tile in the partition kernels' digit scan).
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+#define KK_DPP_ADD(ctrl, rows, bound) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, bound)
+    KK_DPP_ADD(0x111, 0xf, true);   // row_shr:1
+    KK_DPP_ADD(0x112, 0xf, true);   // row_shr:2
+    KK_DPP_ADD(0x114, 0xf, true);   // row_shr:4
+    KK_DPP_ADD(0x118, 0xf, true);   // row_shr:8
+    KK_DPP_ADD(0x142, 0xa, false);  // row_bcast:15 -> rows 1 and 3
+    KK_DPP_ADD(0x143, 0xc, false);  // row_bcast:31 -> rows 2 and 3
+#undef KK_DPP_ADD
+    return v;
+}
+
 // Exclusive scan over the NT threads' values (thread order); total gets the sum.  All threads call it.
 // PRE_SYNCED: the caller has a workgroup barrier between the last read of stmp and this call (saves one here).
 template <bool PRE_SYNCED = false>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *stmp /* NW */, uint32_t &total) {
     const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(inc, d);
-        if (lane >= (uint32_t)d) inc += t;
-    }
+    const uint32_t inc = wave_incl_scan(v);
     if (!PRE_SYNCED) lds_sync();  // stmp may still be read from a previous call
     if (lane == 63) stmp[w] = inc;
     lds_sync();
@@ -436,15 +446,6 @@ __device__ __forceinline__ uint32_t runs_of(uint32_t v, int K) {
     return r & (r >> (K - s));
 }
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d);
-        if (lane >= (uint32_t)d) v += t;
-    }
-    return v;
-}
-
 __global__ __launch_bounds__(HB_NT) void k_hist_bases(BasesArgs a, uint32_t *tilehist, uint32_t n_tiles, uint32_t *rec_total) {
     __shared__ uint32_t hs[HB_NW][RADIX];
     const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(HB_NT) void k_hist_bases(BasesArgs a, uint32_t *til
                 cntA = (uint32_t)__popc(okm & ((fl & (0u - fl)) - 1u));
                 cntB = (uint32_t)__popc(okm & ~((1u << (31 - __clz(fl))) - 1u));
             }
-            const uint32_t sc = wave_incl_scan((fl ? 0u : call) | (nfl << 16), lane);
+            const uint32_t sc = wave_incl_scan((fl ? 0u : call) | (nfl << 16));
             const uint32_t p_incl = sc & 0xFFFFu, f_incl = sc >> 16;
             if (nfl >= 2u) {  // records that start and end inside one word
                 uint32_t f = fl, rec = rec_base + f_incl - nfl;
@@ -618,12 +619,7 @@ __global__ __launch_bounds__(BNT) void k_yscatter(BasesArgs a, const uint32_t *t
         }
         lds_sync();
         // exclusive scan of the 256 digit counts (waves 0..3 hold them), tile total
-        uint32_t dtot = (tid < RADIX) ? cnt[tid] : 0u, inc = dtot;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(inc, o);
-            if (lane >= (uint32_t)o) inc += t;
-        }
+        const uint32_t dtot = (tid < RADIX) ? cnt[tid] : 0u, inc = wave_incl_scan(dtot);
         if (lane == 63) swave[w] = inc;
         lds_sync();
         uint32_t wbase = 0, tile_count = 0;
@@ -1802,12 +1798,7 @@ __global__ __launch_bounds__(DD_NT) void k_dd(DDArgs a, uint32_t *hist, uint32_t
         if (t < t_last) nxw = dd_tile_fetch(a, (t + 1) * DD_C, tid);
         uint32_t inc = 0;
         if constexpr (SCATTER) {  // LDS slot of every digit's first entry = exclusive scan of the row's counts
-            inc = (tid < RADIX) ? gc : 0u;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t x = __shfl_up(inc, o);
-                if (lane >= (uint32_t)o) inc += x;
-            }
+            inc = wave_incl_scan((tid < RADIX) ? gc : 0u);
             if (tid < RADIX && lane == 63) swave[wv] = inc;
         }
         lds_sync();
