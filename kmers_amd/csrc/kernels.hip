@@ -5,7 +5,7 @@
 //                                                                         extract from the 2-bit packed store
 //   count_kmers, atomic ++ into a shared int array (:213-216, :320-328)
 //        -> y, K <= 8: k_count_y_lds (LDS tables, windows shifted out of registers);
-//           y, K >= 9: partition by the top 8 / 16 id bits (k_hist_words_y, k_scatter<..YKEYS..>, for K >= 13 also
+//           y, K >= 9: partition by the top 8 / 16 id bits (k_hist_words_y, k_yscatter, for K >= 13 also
 //           k_hist_entries, k_scatter mode 2, k_bucket_bounds), then per-slice LDS tables (k_count_y_sorted,
 //           k_count_y_overflow); k_count_y_global is the plain-atomics kernel kept for A-B runs.
 //   collect_kmers (unordered_map per isoform) + fill_indices_coo (:218-238)
@@ -584,11 +584,13 @@ __global__ __launch_bounds__(BNT) void k_hist_words_y(BasesArgs a, uint32_t *til
     }
 }
 
-// y for K >= 13, pass 0 partition with 4-byte entries ((sort key >> 8) << 24 | low bits): the order-free scheme of
-// k_scatter<..YKEYS..> (windows from registers, the rank from one returning LDS atomic) in 1024-thread workgroups on
-// tiles of 16,384 positions.  The write-out of this pass is store-bound and its runs are twice as long this way:
-// 2.17 -> 1.79 ms on the bench's reads (the 2-byte payloads of K <= 12 do better with the 8192-position tiles of
-// k_scatter, two workgroups per CU).
+// y for K >= 9, pass 0 partition: sort key = id >> low_bits, payload = the low bits, no records.  K <= 12: 2-byte
+// entries (the payload; the sort key is the region); K >= 13: 4-byte entries ((sort key >> 8) << 24 | low bits).
+// Order-free: a histogram follows, not a run-length reduce, so the windows come from registers (one packed word per
+// thread) and the rank inside a (digit, tile) is what ONE returning LDS atomic on the tile's digit counter hands out.
+// 1024-thread workgroups on tiles of 16,384 positions: the write-out is store-bound and its runs are twice as long as
+// with 8192-position tiles -- 2.17 -> 1.79 ms with 4-byte entries (round 1) and 3.07 -> 2.60 ms per 2^31 positions
+// with 2-byte entries (round 2: 64-byte runs wrote every 128-byte line in two halves, 2.0x WRITE_SIZE in the PMC pass).
 template <class ET, int BNT>
 __global__ __launch_bounds__(BNT) void k_yscatter(BasesArgs a, const uint32_t *tilebase, uint64_t n_words8, uint32_t n_tiles, ET *out) {
     constexpr int BNW = BNT / 64, BTILE = BNT * 16;
@@ -711,21 +713,15 @@ __global__ __launch_bounds__(NT) void k_hist_entries(const ET *ent, const uint32
 // range [b*per, (b+1)*per) and fetches the next tile while the current one is ranked and written.
 //   FROM_BASES: entries are generated from the packed store (pass 0); otherwise read from `in`.
 //   tilebase = exclusive scan of the digit-major tile histogram: global position of the first entry of (digit, tile).
-//   YKEYS (y for K >= 9, narrow entries from the bases): sort key = id >> low_bits, payload = the low bits, no records.
-//   ORDER_FREE (the y path): the entries of a (digit, tile) may land in any order -- a histogram follows, not a
-//   run-length reduce -- so the rank is simply what one returning LDS atomic on the tile's digit counter hands out.
-//   Mode 1: every tile.  Mode 2 (second pass of the y path, whose output must stay ordered by the byte the first pass
-//   sorted on): only tiles that lie inside one region of the input, i.e. all but ~256 of them.
-//   OUT16 (y, one pass, K <= 12): only the low 16 bits of an entry mean anything (the sort key is the region):
-//   `out` is an array of uint16_t.
-template <bool FROM_BASES, class ET, bool YKEYS = false, int ORDER_FREE = 0, bool OUT16 = false>
+//   ORDER_FREE = 2 (second pass of the y path for K >= 13): the entries of a (digit, tile) may land in any order -- a
+//   histogram follows, not a run-length reduce -- so the rank is simply what one returning LDS atomic on the tile's
+//   digit counter hands out; only in tiles that lie inside one region of the input, i.e. all but ~256 of them (the
+//   output must stay ordered by the byte the first pass sorted on).
+template <bool FROM_BASES, class ET, int ORDER_FREE = 0>
 __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, const uint32_t *p_count, int shift,
                                                    const uint32_t *tilebase, uint32_t n_tiles, ET *out, const uint32_t *regions) {
     constexpr bool NARROW = sizeof(ET) == 4;
-    static_assert(!YKEYS || (FROM_BASES && NARROW && ORDER_FREE == 1), "y keys: from the bases, narrow entries, any order");
-    static_assert(ORDER_FREE != 2 || (!FROM_BASES && NARROW), "mode 2 is for the y path's second pass");
-    static_assert(IPT == 16, "one packed word (16 windows) per thread and tile");
-    static_assert(!ORDER_FREE || NARROW, "order-free partition is the y path's: narrow entries");
+    static_assert(ORDER_FREE == 0 || (ORDER_FREE == 2 && !FROM_BASES && NARROW), "mode 2 is for the y path's second pass");
     // entry staging; its first NW*RADIX 8-byte words double as the match masks (below)
     __shared__ __attribute__((aligned(16))) ET sent[TILE];
     __shared__ uint8_t saux[NARROW ? TILE : 4];  // narrow: pass 0 the partition digit, pass 1 the byte that replaces it
@@ -750,7 +746,6 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
     ET e[IPT];
     uint32_t aux[IPT];   // narrow pass 1: the region (= previous digit) of each entry, found when the load is issued
     TilePf pf;
-    WordWindows ww{0u, 0u, 0u};  // YKEYS: this thread's packed word of the next tile (windows decoded from registers)
     // entries of tile t (the wave's 16 rounds) into e[]; narrow: their regions into aux[].  A wave's 1024 entries lie
     // in one region nearly always (256 regions): one wave-uniform test instead of an LDS walk per entry.
     auto load_tile = [&](uint32_t t) {
@@ -777,9 +772,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
             }
         }
     };
-    if (YKEYS) {
-        ww = word_fetch(a, (a.tile0 + t0) * NT + tid);
-    } else if (FROM_BASES) {
+    if (FROM_BASES) {
         pf = tile_fetch<true>(a, t0);
     } else {
         if constexpr (NARROW) {
@@ -793,7 +786,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
     KK_STAMP_BEGIN();
     for (uint32_t tile = t0; tile < t1; ++tile) {
         const uint64_t base = (uint64_t)tile * TILE;
-        bool of = ORDER_FREE == 1;  // workgroup-uniform
+        bool of = false;  // workgroup-uniform
         if constexpr (ORDER_FREE == 2) {
             const uint32_t r = region_search(sreg, (uint32_t)base);
             const uint64_t tile_last = (base + TILE < E) ? base + TILE : E;
@@ -807,11 +800,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
                 smask[i] = 0ull;  // the match masks must start (and, by construction, end) a tile all zero
             }
         }
-        WordWindows wcur = ww;
-        if (YKEYS) {
-            if (tile + 1 < t1) ww = word_fetch(a, (a.tile0 + tile + 1) * NT + tid);
-            lds_sync();
-        } else if (FROM_BASES) {
+        if (FROM_BASES) {
             tile_commit<true>(L, pf, stmp);
             if (tile + 1 < t1) pf = tile_fetch<true>(a, tile + 1);
         } else {
@@ -834,14 +823,8 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
                 const uint32_t o = wl + j * 64;
                 uint32_t key;
                 uint32_t col;
-                if constexpr (YKEYS) {  // window j of this thread's word: any order will do
-                    ok = word_window(wcur, j, a.K, key);
-                    col = key & ((1u << a.low_bits) - 1u);
-                    key >>= a.low_bits;
-                } else {
-                    ok = window_at(L, o, a.K, key);
-                    col = record_at(L, o);  // (the readlane variant of k_hist_bases costs 3 VGPRs here: spills, slower)
-                }
+                ok = window_at(L, o, a.K, key);
+                col = record_at(L, o);  // (a wave-uniform readlane lookup costs 3 VGPRs here: spills, slower)
                 asm volatile("" : "+v"(col));  // finish the column now: sunk to its use it keeps 4 LDS words per round alive
                 if constexpr (NARROW) {
                     d = key & 255u;
@@ -957,10 +940,7 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
                 d = __builtin_amdgcn_ubfe(entry_key((u64)v), (uint32_t)shift, 8u);
             }
             if (KK_ABLATE(1)) continue;
-            if constexpr (OUT16)
-                reinterpret_cast<uint16_t *>(out)[gadj[d] + i] = (uint16_t)v;
-            else
-                out[gadj[d] + i] = v;
+            out[gadj[d] + i] = v;
         }
         KK_STAMP(6);  // write-out
         lds_sync();
@@ -2623,11 +2603,8 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         const uint32_t *c_hist = hist, *c_E = &scal[0];
         // pass 0 tiles: 8192 positions (512 threads) for the 2-byte payloads, 16,384 (1024 threads) for 4-byte entries
         const uint64_t n_words8 = (uint64_t)nt * NT;
-        const uint32_t nt0 = two_pass ? (nt + 1) / 2 : nt;
-        if (two_pass)
-            hipLaunchKernelGGL(k_hist_words_y<1024>, dim3(nt0 < 1024u ? nt0 : 1024u), dim3(1024), 0, s, a, hist, n_words8, nt0);
-        else
-            hipLaunchKernelGGL(k_hist_words_y<NT>, hgrid, block, 0, s, a, hist, n_words8, nt0);
+        const uint32_t nt0 = (nt + 1) / 2;
+        hipLaunchKernelGGL(k_hist_words_y<1024>, dim3(nt0 < 1024u ? nt0 : 1024u), dim3(1024), 0, s, a, hist, n_words8, nt0);
         pt.mark("k_hist_words_y");
         if (int rc = scan_tilehist(hist, nt0, bsum, &scal[0], s)) return rc;
         pt.mark("k_scan");
@@ -2635,8 +2612,7 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         if (two_pass)
             hipLaunchKernelGGL((k_yscatter<uint32_t, 1024>), dim3(nt0 < 256u ? nt0 : 256u), dim3(1024), 0, s, a, c_hist, n_words8, nt0, entA);
         else  // one pass: 2-byte payloads
-            hipLaunchKernelGGL((k_scatter<true, uint32_t, true, 1, true>), pgrid, block, 0, s, a, (const uint32_t *)nullptr, c_E, 0,
-                               c_hist, nt, entA, (const uint32_t *)nullptr);
+            hipLaunchKernelGGL((k_yscatter<uint16_t, 1024>), dim3(nt0 < 512u ? nt0 : 512u), dim3(1024), 0, s, a, c_hist, n_words8, nt0, (uint16_t *)entA);
         pt.mark("k_scatter<bases,y>");
         const uint32_t *sorted = entA, *final_regions = regs0;
         if (two_pass) {
@@ -2646,7 +2622,7 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
             pt.mark("k_scan");
             hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, nt, c_E, regs1);
             // this pass keeps the order of the byte pass 0 sorted on (k_count_y_sorted searches a region by it): mode 2
-            hipLaunchKernelGGL((k_scatter<false, uint32_t, false, 2>), pgrid, block, 0, s, a, (const uint32_t *)entA, c_E, 8, c_hist, nt, entB,
+            hipLaunchKernelGGL((k_scatter<false, uint32_t, 2>), pgrid, block, 0, s, a, (const uint32_t *)entA, c_E, 8, c_hist, nt, entB,
                                (const uint32_t *)regs0);
             pt.mark("k_scatter<entries>");
             sorted = entB;
