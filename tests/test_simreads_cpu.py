@@ -77,6 +77,28 @@ def test_isoform_list_follows_fasta_py(tmp_path, L):
         assert sum((q.sequences() for q in parts), []) == want
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_isoform_list_fuzz(tmp_path, seed):
+    """Random files from an alphabet of bases, '>' , every line end and every blank python strips: the store under the
+    fasta.py rules == the restated fasta.py reader, whole and in byte-range shards."""
+    from kmers_amd.store import MODE_FASTA_PY, Store
+    rng = np.random.default_rng(900 + seed)
+    alphabet = [b"A", b"C", b"G", b"T", b"N", b"a", b">", b"\n", b"\r", b"\r\n", b" ", b"\t", b"\x0b", b"\x0c", b"\x1c", b"\x1f",
+                b"\x00", b"PREDICTED", b">h", b"\n>rec ", b"ACGTACGTAC"]
+    weights = np.array([8, 8, 8, 8, 1, 1, 0.3, 2, 0.7, 0.7, 1, 0.5, 0.2, 0.2, 0.2, 0.2, 0.2, 0.2, 0.5, 1.5, 6], float)
+    text = b"".join(alphabet[i] for i in rng.choice(len(alphabet), int(rng.integers(0, 3000)), p=weights / weights.sum()))
+    if rng.random() < 0.5:
+        text = b">first\n" + text
+    p = tmp_path / "f.fsa"
+    p.write_bytes(text)
+    for L in (0, 7, 40):
+        want = [_norm(q) for _, q in orc.kept_isoforms(str(p), L)]
+        assert Store(str(p), MODE_FASTA_PY, L=L).sequences() == want, (seed, L)
+        for n in (2, 5):
+            got = sum((Store(str(p), MODE_FASTA_PY, L=L, shard=r, n_shards=n, by_bytes=True).sequences() for r in range(n)), [])
+            assert got == want, (seed, L, n)
+
+
 def test_first_header_empty_means_no_records(tmp_path):
     from kmers_amd.store import MODE_FASTA_PY, Store
     for text in (b">\nACGT\n>b\nACGT\n", b">  \t \r\nACGT\n>b\nACGT\n", b"", b"no header at all\nACGT\n", b"x>a\nACGT\n"):
