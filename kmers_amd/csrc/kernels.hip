@@ -62,7 +62,13 @@ constexpr int RADIX = 256;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int FILL_INLINE = 32;          // row-pointer gaps up to this many rows are filled by the finding lane
 constexpr uint64_t FILL_CHUNK = 1 << 16; // longer gaps become tasks of at most this many rows
-constexpr int PERSIST_BLOCKS = 512;      // persistent grids: two 512-thread workgroups per CU
+#ifndef KK_HIST_BLOCKS
+#define KK_HIST_BLOCKS 8192
+#endif
+#ifndef KK_PERSIST_BLOCKS
+#define KK_PERSIST_BLOCKS 8192
+#endif
+constexpr int PERSIST_BLOCKS = KK_PERSIST_BLOCKS;  // workgroups of the partition kernels: each walks a contiguous tile range (512 = one resident set: 1.41 ms; 8192: 1.17 ms for k_scatter<entries> on config 2 -- the tail balances)
 
 static_assert(TILE / 16 == NT, "one packed-bases word per thread per tile");
 static_assert(TILE % 64 == 0, "tile must be a whole number of wave rounds");
@@ -432,6 +438,18 @@ __global__ __launch_bounds__(YL_NT) void k_count_y_lds(BasesArgs a, int32_t *cou
 // (all but ~1 in 150 on a transcriptome) add their windows to a wave-wide sum that is carried in a scalar from group to
 // group and flushed with ONE atomic when a record ends or the tile does; words with starts split their windows between
 // the records around them with one segmented sum over the wave's lanes.
+#ifndef HB_BLOCKS
+#define HB_BLOCKS 8192
+#endif
+#ifndef YS16_BLOCKS
+#define YS16_BLOCKS 32768
+#endif
+#ifndef YS32_BLOCKS
+#define YS32_BLOCKS 256
+#endif
+#ifndef HW_BLOCKS
+#define HW_BLOCKS 4096
+#endif
 constexpr int HB_NT = 256, HB_NW = HB_NT / 64;
 constexpr int HB_GROUPS = TILE / (64 * 16);  // groups of 64 words per tile
 
@@ -2599,20 +2617,20 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         const uint32_t cap = (uint32_t)(cap64 > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap64);
         const dim3 grid(nt);
         const dim3 pgrid(nt < (uint32_t)PERSIST_BLOCKS ? nt : (uint32_t)PERSIST_BLOCKS);
-        const dim3 hgrid(nt < 2048u ? nt : 2048u);
+        const dim3 hgrid(nt < (uint32_t)KK_HIST_BLOCKS ? nt : (uint32_t)KK_HIST_BLOCKS);
         const uint32_t *c_hist = hist, *c_E = &scal[0];
         // pass 0 tiles: 8192 positions (512 threads) for the 2-byte payloads, 16,384 (1024 threads) for 4-byte entries
         const uint64_t n_words8 = (uint64_t)nt * NT;
         const uint32_t nt0 = (nt + 1) / 2;
-        hipLaunchKernelGGL(k_hist_words_y<1024>, dim3(nt0 < 1024u ? nt0 : 1024u), dim3(1024), 0, s, a, hist, n_words8, nt0);
+        hipLaunchKernelGGL(k_hist_words_y<1024>, dim3(nt0 < (uint32_t)HW_BLOCKS ? nt0 : (uint32_t)HW_BLOCKS), dim3(1024), 0, s, a, hist, n_words8, nt0);
         pt.mark("k_hist_words_y");
         if (int rc = scan_tilehist(hist, nt0, bsum, &scal[0], s)) return rc;
         pt.mark("k_scan");
         hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, nt0, c_E, regs0);
         if (two_pass)
-            hipLaunchKernelGGL((k_yscatter<uint32_t, 1024>), dim3(nt0 < 256u ? nt0 : 256u), dim3(1024), 0, s, a, c_hist, n_words8, nt0, entA);
+            hipLaunchKernelGGL((k_yscatter<uint32_t, 1024>), dim3(nt0 < (uint32_t)YS32_BLOCKS ? nt0 : (uint32_t)YS32_BLOCKS), dim3(1024), 0, s, a, c_hist, n_words8, nt0, entA);
         else  // one pass: 2-byte payloads
-            hipLaunchKernelGGL((k_yscatter<uint16_t, 1024>), dim3(nt0 < 512u ? nt0 : 512u), dim3(1024), 0, s, a, c_hist, n_words8, nt0, (uint16_t *)entA);
+            hipLaunchKernelGGL((k_yscatter<uint16_t, 1024>), dim3(nt0 < (uint32_t)YS16_BLOCKS ? nt0 : (uint32_t)YS16_BLOCKS), dim3(1024), 0, s, a, c_hist, n_words8, nt0, (uint16_t *)entA);
         pt.mark("k_scatter<bases,y>");
         const uint32_t *sorted = entA, *final_regions = regs0;
         if (two_pass) {
@@ -2769,7 +2787,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     BasesArgs a{d_bases, d_valid, flags, tilecb, bases_words, vw, n_pos, K};
     const dim3 grid(l.n_tiles), block(NT);
     const dim3 pgrid(l.n_tiles < (uint32_t)PERSIST_BLOCKS ? l.n_tiles : (uint32_t)PERSIST_BLOCKS);
-    const dim3 hgrid(l.n_tiles < 2048u ? l.n_tiles : 2048u);
+    const dim3 hgrid(l.n_tiles < (uint32_t)KK_HIST_BLOCKS ? l.n_tiles : (uint32_t)KK_HIST_BLOCKS);
     const int n_pass = (2 * K + 7) / 8;
 
     // K <= 8 and at most 2^24 records: 4-byte entries (digit byte << 24 | column), else 8-byte (k-mer id << 32 | column)
@@ -2778,7 +2796,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     const uint32_t *c_hist = hist, *c_E = &scal[0];
 
     // pass 0: packed bases -> instances partitioned by the lowest digit
-    hipLaunchKernelGGL(k_hist_bases, dim3(l.n_tiles < 4096u ? (l.n_tiles + HB_NW - 1) / HB_NW : 1024u), dim3(HB_NT), 0, s, a, hist, l.n_tiles, total);
+    hipLaunchKernelGGL(k_hist_bases, dim3(l.n_tiles < 4u * HB_BLOCKS ? (l.n_tiles + HB_NW - 1) / HB_NW : (uint32_t)HB_BLOCKS), dim3(HB_NT), 0, s, a, hist, l.n_tiles, total);
     pt.mark("k_hist_bases");
     if (int rc = scan_tilehist(hist, l.n_tiles, bsum, &scal[0], s)) return rc;
     pt.mark("k_scan");
