@@ -1624,7 +1624,10 @@ __global__ __launch_bounds__(NT) void k_fill_tasks(uint64_t *row_ind, const Fill
 constexpr int DD_NT = 1024;          // one workgroup per CU
 constexpr int DD_W = 6;              // windows per thread and tile
 constexpr int DD_C = DD_NT * DD_W;   // positions per tile = capacity of the entry staging
-constexpr int DD_GRID = 256;
+#ifndef KK_DD_GRID
+#define KK_DD_GRID 1024
+#endif
+constexpr int DD_GRID = KK_DD_GRID;
 constexpr uint32_t DD_MAX_REC = 1u << 22;   // columns fit 22 bits, so the count field has at least 2
 
 struct DDArgs {
