@@ -67,6 +67,36 @@ def test_csr_merge_unit():
     assert np.array_equal(np.diff(row.astype(np.int64)), np.bincount(r, minlength=n_rows))
 
 
+def test_csr_place_unit():
+    """kmers_csr_place, one call per "rank" into one shared output, == kmers_csr_merge of the same parts (empty parts and
+    empty rows included)."""
+    from kmers_amd import _lib
+    from kmers_amd.distributed import merge_csr_parts
+    lib = _lib.handle()
+    rng = np.random.default_rng(8)
+    n_rows, parts = 300, []
+    for g in range(5):
+        dens = 0.0 if g == 2 else 0.15
+        d = (rng.random((n_rows, 9)) < dens) * rng.random((n_rows, 9))
+        d[100:180] = 0
+        r, c = np.nonzero(d)
+        row = np.zeros(n_rows + 1, np.uint64)
+        np.add.at(row, r + 1, 1)
+        parts.append((d[r, c].astype(np.float32), np.cumsum(row).astype(np.uint64), (c + 9 * g).astype(np.uint64)))
+    want = merge_csr_parts(parts, n_rows)
+    glob = np.sum([p[1] for p in parts], axis=0).astype(np.uint64)
+    total = int(glob[-1])
+    out_d, out_c, out_r = np.zeros(total, np.float32), np.zeros(total, np.uint64), np.zeros(n_rows + 1, np.uint64)
+    before = np.zeros(n_rows + 1, np.uint64)
+    for g, (d, r, c) in enumerate(parts):
+        rc = lib.kmers_csr_place(n_rows, r.ctypes.data, before.ctypes.data, glob.ctypes.data, d.ctypes.data if d.size else None,
+                                 c.ctypes.data if c.size else None, out_d.ctypes.data, out_c.ctypes.data,
+                                 out_r.ctypes.data if g == 0 else None)
+        assert rc == 0
+        before = before + r
+    assert np.array_equal(out_r, want[1]) and np.array_equal(out_c, want[2]) and np.array_equal(out_d, want[0])
+
+
 def _run_model_workers(mode, world, iso, reads, K, out, timeout=300):
     port = _free_port()
     procs = []
