@@ -172,6 +172,8 @@ int kmers_csr_merge(int n_parts, uint64_t n_rows, const float *const data[], con
  *   out[global_row_ind[r] + (before[r + 1] - before[r]) ...]  for every row r,
  * where global_row_ind = sum over ranks of row_ind and before = sum of row_ind over the ranks in front of this one (both
  * u64[n_rows + 1]; kmers_amd.distributed.concat_x_shards gets them from one all-reduce and a prefix over the ranks).
+ * before may be NULL: global_row_ind[r] is then taken as the finished destination of row r (the caller has added the
+ * earlier ranks' counts itself, e.g. on the device) and out_row_ind must be NULL.
  * out_row_ind, when not NULL, receives global_row_ind (rank 0).  Host memory; all host threads. */
 int kmers_csr_place(uint64_t n_rows, const uint64_t *row_ind, const uint64_t *before, const uint64_t *global_row_ind,
                     const float *data, const uint64_t *col_ind, float *out_data, uint64_t *out_col_ind,

@@ -523,7 +523,7 @@ int kmers_csr_merge(int n_parts, uint64_t n_rows, const float *const data[], con
 
 int kmers_csr_place(uint64_t n_rows, const uint64_t *row_ind, const uint64_t *before, const uint64_t *global_row_ind,
                     const float *data, const uint64_t *col_ind, float *out_data, uint64_t *out_col_ind, uint64_t *out_row_ind) {
-    if (!row_ind || !before || !global_row_ind || !out_data || !out_col_ind) return KMERS_ERR_BAD_ARG;
+    if (!row_ind || !global_row_ind || !out_data || !out_col_ind) return KMERS_ERR_BAD_ARG;
     if (out_row_ind)
         kmers::parallel_for((size_t)n_rows + 1, 1u << 18, [&](size_t lo, size_t hi) {
             memcpy(out_row_ind + lo, global_row_ind + lo, (hi - lo) * 8);
@@ -532,7 +532,7 @@ int kmers_csr_place(uint64_t n_rows, const uint64_t *row_ind, const uint64_t *be
         for (size_t r = lo; r < hi; ++r) {
             const uint64_t a = row_ind[r], n = row_ind[r + 1] - a;
             if (!n) continue;
-            const uint64_t at = global_row_ind[r] + (before[r + 1] - before[r]);
+            const uint64_t at = global_row_ind[r] + (before ? before[r + 1] - before[r] : 0);
             memcpy(out_col_ind + at, col_ind + a, (size_t)n * 8);
             memcpy(out_data + at, data + a, (size_t)n * 4);
         }

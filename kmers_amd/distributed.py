@@ -152,8 +152,13 @@ def concat_x_shards(data, col_ind, row_ind, nnz, n_rows, gloo=False):
         pinned.append(h)
         return h.numpy()                     # valid after the synchronize below
 
+    # destination of this rank's row r = global start of the row + the row's entries on the ranks in front: formed where the
+    # vectors are (on the GPU with RCCL), so only two row vectors cross PCIe (three on rank 0, which keeps the pointer)
+    dst = glob[:-1] + (before[1:] - before[:-1])
+    del before
     h_data, h_col = to_host(data, nnz), to_host(col_ind, nnz)
-    h_row, h_glob, h_before = to_host(row_ind, n_rows + 1), to_host(glob, n_rows + 1), to_host(before, n_rows + 1)
+    h_row, h_dst = to_host(row_ind, n_rows + 1), to_host(dst, n_rows)
+    h_glob = to_host(glob, n_rows + 1) if rank == 0 else None
     if pinned:
         torch.cuda.synchronize()
     # the shared output: three files in /dev/shm mapped by every rank, unlinked as soon as all ranks have written (the
@@ -189,9 +194,10 @@ def concat_x_shards(data, col_ind, row_ind, nnz, n_rows, gloo=False):
     try:
         o_data, o_col, o_row = (np.memmap(base[0] + ".%d" % i, dtype=dt, mode="r+", shape=(n,))
                                 for i, (n, dt) in enumerate(shapes))
-        rc = lib.kmers_csr_place(n_rows, h_row.ctypes.data, h_before.ctypes.data, h_glob.ctypes.data, h_data.ctypes.data,
-                                 h_col.ctypes.data, o_data.ctypes.data, o_col.ctypes.data,
-                                 o_row.ctypes.data if rank == 0 else None)
+        rc = lib.kmers_csr_place(n_rows, h_row.ctypes.data, None, h_dst.ctypes.data, h_data.ctypes.data, h_col.ctypes.data,
+                                 o_data.ctypes.data, o_col.ctypes.data, None)
+        if rank == 0:
+            o_row[:] = h_glob.view(np.uint64)
         dist.barrier()
     finally:
         if rank == 0:
