@@ -1,12 +1,12 @@
 """`multinomial_simplex_model` with the reference's constructor and `logp_grad` (reference
 kmerexpr/multinomial_simplex_model.py:10-95, kmerexpr/utils.py:76-108), X and y resident in HBM.
 
-What is here: the constructor, `logp_grad(theta, nograd)`, `initialize_iterates_uniform`, and a `fit` that hands
-`self.logp_grad` to the reference's own solvers (exp_grad_solver / mg, imported from an installed `kmerexpr`: they are
-host-side Python outside this library's scope and only ever call `logp_grad`).  What is NOT here: the attributes
-`ymask / xnnz / ynnz / scratch` (X and y live in HBM, `self.device_model`), `initialize_iterates_Xy` and
-`initialize_iterates_lsq` (they need the host copies; `fit` says so when `model_parameters.init_iterates` asks for
-them).  The log term is accumulated in float64 where the reference's numba loop works on its float32 scratch:
+What is here: the constructor, `logp_grad(theta, nograd)`, the three `initialize_iterates_*` starts and a `fit` that
+hands `self.logp_grad` to the reference's own solvers (exp_grad_solver / mg, imported from an installed `kmerexpr`: they
+are host-side Python outside this library's scope and only ever call `logp_grad`).  X and y live in HBM
+(`self.device_model`), so the attributes `ymask / xnnz / ynnz / scratch` do not exist: `initialize_iterates_Xy` is one
+`w . xnnz` product on the device, `initialize_iterates_lsq` (scipy's lsqr, host-side as in the reference) builds its
+host copy of xnnz when it is called.  The log term is accumulated in float64 where the reference's numba loop works on its float32 scratch:
 agreement to float32 rounding, not bit parity (tests/test_model_gpu.py states the tolerance)."""
 import numpy as np
 
@@ -32,6 +32,7 @@ class multinomial_simplex_model:
         else:
             self.lengths = np.ones(self.T)
         self._torch = torch
+        self._x, self._y = x, y                      # (references, for initialize_iterates_lsq only)
         self.device_model = DeviceModel.from_host(x, y, device)
         self._theta = torch.empty(self.T, dtype=torch.float32, device=self.device_model.device)
 
@@ -60,15 +61,31 @@ class multinomial_simplex_model:
         alpha = np.ones(self.T)
         return alpha / alpha.sum()
 
+    def initialize_iterates_Xy(self):
+        """reference multinomial_simplex_model.py:103-106: theta0 = ynnz @ xnnz, normalised.  On the device: the gradient
+        product with x.theta = 1, i.e. w = ynnz."""
+        torch = self._torch
+        ones = torch.ones(self.device_model.n_masked, dtype=torch.float32, device=self.device_model.device)
+        theta0 = self.device_model.grad_from(ones)[1].double().cpu().numpy()
+        return theta0 / theta0.sum()
+
+    def initialize_iterates_lsq(self, iterations=200, mult_fact_neg=10):
+        """reference multinomial_simplex_model.py:108-115 (scipy lsqr on the host, then negatives lifted and normalised)."""
+        from scipy.sparse.linalg import lsqr
+        ymask = self._y.nonzero()
+        xnnz = self._x.tocsr()[ymask]
+        ynnz = self._y[ymask] / np.sum(self._y)
+        theta0 = lsqr(xnnz, ynnz / self.N, iter_lim=iterations)[0]
+        theta0[theta0 <= 0] = np.min(theta0[theta0 > 0]) / mult_fact_neg
+        return theta0 / theta0.sum()
+
     def fit(self, model_parameters, theta0=None, tol=1e-20, gtol=1e-20, n_iters=100, opt_method="mg"):
         """The reference's dispatch (multinomial_simplex_model.py:117-146) onto its own solvers, which must be importable
-        (`kmerexpr.exp_grad_solver`, `kmerexpr.mg`); only the uniform start is available without the host copies."""
+        (`kmerexpr.exp_grad_solver`, `kmerexpr.mg`)."""
         if theta0 is None:
             init = getattr(model_parameters, "init_iterates", "uniform")
-            if init in ("lsq", "Xy"):
-                raise NotImplementedError("init_iterates=%r needs xnnz / ynnz on the host; pass theta0, or use the "
-                                          "uniform start" % init)
-            theta0 = self.initialize_iterates_uniform()
+            theta0 = (self.initialize_iterates_lsq() if init == "lsq" else
+                      self.initialize_iterates_Xy() if init == "Xy" else self.initialize_iterates_uniform())
         try:  # the reference's imports (multinomial_simplex_model.py:3-4)
             from kmerexpr.exp_grad_solver import exp_grad_solver
             from kmerexpr.mg import mg

@@ -107,6 +107,44 @@ def test_beta_terms_and_lengths(syn):
         check(model, x, y, theta, beta=1.5, lengths=lengths)
 
 
+def test_starts_and_fit_dispatch(syn):
+    """initialize_iterates_Xy / _lsq against the reference's formulas on the host copies (multinomial_simplex_model.py:
+    97-115), and fit() handing logp_grad to a solver (a stand-in module: kmerexpr is not installed here)."""
+    import sys
+    import types
+    from scipy.sparse.linalg import lsqr
+    from kmers_amd.multinomial_simplex_model import multinomial_simplex_model
+    x, y = xy(syn, 6)
+    model = multinomial_simplex_model(x, y)
+    ymask, xnnz, ynnz = orc.model_setup(x, y)
+    want = np.asarray(ynnz @ xnnz).ravel()
+    np.testing.assert_allclose(model.initialize_iterates_Xy(), want / want.sum(), rtol=1e-5, atol=1e-12)
+    t = lsqr(xnnz.astype(np.float32), ynnz / model.N, iter_lim=50)[0]
+    t[t <= 0] = np.min(t[t > 0]) / 10
+    np.testing.assert_allclose(model.initialize_iterates_lsq(iterations=50), t / t.sum(), rtol=1e-4, atol=1e-10)
+    seen = {}
+    def solver(fn, theta0, **kw):
+        seen.update(kw, start=theta0, val=fn(theta0, nograd=True))
+        return {"x": theta0}
+    pkg, eg, mgm = types.ModuleType("kmerexpr"), types.ModuleType("kmerexpr.exp_grad_solver"), types.ModuleType("kmerexpr.mg")
+    eg.exp_grad_solver, mgm.mg = solver, (lambda fn, theta0, tol, max_iter: solver(fn, theta0, tol=tol, max_iter=max_iter))
+    old = {k: sys.modules.get(k) for k in ("kmerexpr", "kmerexpr.exp_grad_solver", "kmerexpr.mg")}
+    sys.modules.update({"kmerexpr": pkg, "kmerexpr.exp_grad_solver": eg, "kmerexpr.mg": mgm})
+    try:
+        params = types.SimpleNamespace(init_iterates="Xy", lrs="warmstart")
+        model.fit(params, n_iters=7, opt_method="exp_grad")
+        assert seen["n_iters"] == 7 and seen["lrs"] == "warmstart" and np.isfinite(seen["val"])
+        np.testing.assert_allclose(seen["start"], want / want.sum(), rtol=1e-5, atol=1e-12)
+        model.fit(types.SimpleNamespace(init_iterates="uniform"), n_iters=3)
+        assert seen["max_iter"] == 3 and np.allclose(seen["start"], 1.0 / model.T)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 def test_columns_are_stochastic(syn):
     """The reference's test_simplex (test/test_transcriptome_reader.py:52-64): sum(X . theta) == 1 on the simplex.
     At K=3 every row has a read, so xnnz is all of X."""
