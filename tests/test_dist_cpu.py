@@ -20,9 +20,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,K", [(2, 8), (3, 5)])
-def test_sharded_y_and_x_equal_whole(oracle, tmp_path, world, K):
-    files = [os.path.join(kmtest.INP, "syn_small.fsa"), os.path.join(kmtest.INP, "ref_test4.fsa")]
+@pytest.mark.parametrize("world,K,names", [(2, 8, ("syn_small.fsa", "ref_test4.fsa")), (3, 5, ("syn_small.fsa", "ref_test4.fsa")),
+                                           (4, 2, ("ref_test2.fsa", "ref_test4.fsa"))])   # six records on four ranks: empty shards
+def test_sharded_y_and_x_equal_whole(oracle, tmp_path, world, K, names):
+    files = [os.path.join(kmtest.INP, n) for n in names]
     out = str(tmp_path / "res.npz")
     port = _free_port()
     procs = []
