@@ -141,26 +141,42 @@ def concat_x_shards(data, col_ind, row_ind, nnz, n_rows, gloo=False):
     dist.all_reduce(glob, op=dist.ReduceOp.SUM)
     before = _rank_prefix(row_c, dist, rank, world)
     total = int(glob[-1].item())
-    # this rank's shard on the host (pinned when it comes from the GPU: the copy then runs at the link's rate)
-    pinned = []
+    def all_ok(err):
+        """Every rank learns whether any rank failed its local step, so that all of them leave together (a rank that
+        raised on its own would leave the others waiting in the next collective)."""
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32)
+        if on_gpu:
+            flag = flag.cuda()
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            raise RuntimeError("concat_x_shards: %s" % (err if err is not None else "another rank failed"))
 
+    # this rank's shard on the host (pinned when it comes from the GPU: the copy then runs at the link's rate; pageable if
+    # the pinned allocation is refused)
     def to_host(t, n):
         if not t.is_cuda:
             return t[:n].contiguous().numpy()
-        h = torch.empty(n, dtype=t.dtype, pin_memory=True)
+        try:
+            h = torch.empty(n, dtype=t.dtype, pin_memory=True)
+        except RuntimeError:
+            h = torch.empty(n, dtype=t.dtype)
         h.copy_(t[:n], non_blocking=True)
-        pinned.append(h)
         return h.numpy()                     # valid after the synchronize below
 
-    # destination of this rank's row r = global start of the row + the row's entries on the ranks in front: formed where the
-    # vectors are (on the GPU with RCCL), so only two row vectors cross PCIe (three on rank 0, which keeps the pointer)
-    dst = glob[:-1] + (before[1:] - before[:-1])
-    del before
-    h_data, h_col = to_host(data, nnz), to_host(col_ind, nnz)
-    h_row, h_dst = to_host(row_ind, n_rows + 1), to_host(dst, n_rows)
-    h_glob = to_host(glob, n_rows + 1) if rank == 0 else None
-    if pinned:
-        torch.cuda.synchronize()
+    err = None
+    try:
+        # destination of this rank's row r = global start of the row + the row's entries on the ranks in front: formed where
+        # the vectors are (on the GPU with RCCL), so only two row vectors cross PCIe (three on rank 0, which keeps the pointer)
+        dst = glob[:-1] + (before[1:] - before[:-1])
+        del before
+        h_data, h_col = to_host(data, nnz), to_host(col_ind, nnz)
+        h_row, h_dst = to_host(row_ind, n_rows + 1), to_host(dst, n_rows)
+        h_glob = to_host(glob, n_rows + 1) if rank == 0 else None
+        if row_ind.is_cuda:
+            torch.cuda.synchronize()
+    except (RuntimeError, MemoryError) as e:
+        err = e
+    all_ok(err)
     # the shared output: three files in /dev/shm mapped by every rank, unlinked as soon as all ranks have written (the
     # mapping rank 0 returns keeps the pages until its arrays go)
     shapes = ((max(total, 1), np.float32), (max(total, 1), np.uint64), (n_rows + 1, np.uint64))
@@ -191,14 +207,20 @@ def concat_x_shards(data, col_ind, row_ind, nnz, n_rows, gloo=False):
     if base[0] is None:                               # (every rank raises: no collective is left half done)
         raise RuntimeError("concat_x_shards: no room for the whole matrix (%d non-zeros) in %s or %s"
                            % (total, _SHM_DIR, tempfile.gettempdir()))
+    err, out = None, None
     try:
         o_data, o_col, o_row = (np.memmap(base[0] + ".%d" % i, dtype=dt, mode="r+", shape=(n,))
                                 for i, (n, dt) in enumerate(shapes))
         rc = lib.kmers_csr_place(n_rows, h_row.ctypes.data, None, h_dst.ctypes.data, h_data.ctypes.data, h_col.ctypes.data,
                                  o_data.ctypes.data, o_col.ctypes.data, None)
+        _lib.check(rc, "kmers_csr_place")
         if rank == 0:
             o_row[:] = h_glob.view(np.uint64)
-        dist.barrier()
+            out = (o_data[:total], o_row, o_col[:total])
+    except (OSError, ValueError, RuntimeError, MemoryError) as e:
+        err = e
+    try:
+        all_ok(err)                                   # (also the barrier: every rank has written its rows)
     finally:
         if rank == 0:
             for i in range(3):
@@ -206,10 +228,7 @@ def concat_x_shards(data, col_ind, row_ind, nnz, n_rows, gloo=False):
                     os.unlink(base[0] + ".%d" % i)
                 except OSError:
                     pass
-    _lib.check(rc, "kmers_csr_place")
-    if rank != 0:
-        return None
-    return o_data[:total], o_row, o_col[:total]
+    return out
 
 
 def build_x_sharded(files, K, L=0, concatenate_subseq=False, device=None, build_fn=None):
