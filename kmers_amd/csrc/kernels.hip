@@ -1372,6 +1372,11 @@ __global__ __launch_bounds__(RNT, 4) void k_rle(const ET *ent, uint32_t *scal, u
     __shared__ uint32_t s_cnt[RNW], s_first[RNW];
     __shared__ uint32_t s_next;   // first head after this tile (index), E if none
     __shared__ u64 s_out0;        // heads before this tile
+    // cooperative row-pointer fill (below): per wave, a bitmap of the rows that start in a round, its word prefix, and
+    // the output index of every row head of the round
+    constexpr bool COOP_FILL = !NARROW;  // (4-byte entries mean K <= 8: at most 65,536 row heads in all)
+    __shared__ uint32_t s_rbits[COOP_FILL ? RNW : 1][64], s_rpre[COOP_FILL ? RNW : 1][64];
+    __shared__ u64 s_rout[COOP_FILL ? RNW : 1][64];
     const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
     uint32_t *p_nnz = &scal[1], *p_ntasks = &scal[2], *p_err = &scal[3];
     const uint32_t E = scal[0];
@@ -1532,6 +1537,47 @@ __global__ __launch_bounds__(RNT, 4) void k_rle(const ET *ent, uint32_t *scal, u
         ET prev = __shfl_up(e[j], 1);
         const ET prev0 = (j > 0) ? __shfl(e[j > 0 ? j - 1 : 0], 63) : carry0;
         if (lane == 0) prev = prev0;
+        // ---- rows that start in this round, filled by the whole wave.  The row heads of a round cover a contiguous range
+        // of rows (head h owns the rows after the previous head's k-mer up to its own), so when there are many of them
+        // -- large K: most heads are row heads, and on a column shard the gaps between them are several rows long --
+        // the wave writes row_ind[first .. last] in coalesced 512-byte stores: every row looks up how many row heads lie
+        // below it (a bitmap of the heads' rows + word prefix) and takes that head's output index.  A lane filling its
+        // own gap (fill_rows) costs one partly filled store instruction per row of the LONGEST gap in the wave.
+        bool coop = false;
+        constexpr uint32_t COOP_MIN_HEADS = 8, COOP_MAX_ROWS = 2048;
+        const u64 rmask = rm[j];
+        if (COOP_FILL && (uint32_t)__popcll(rmask) >= COOP_MIN_HEADS) {  // wave-uniform
+            const bool rh = (rmask >> lane) & 1ull;
+            const uint32_t kk = rh ? key_of(i, e[j]) : 0u;
+            const uint64_t lo_mine = (rh && i != 0) ? (uint64_t)key_of(i - 1, prev) + 1 : 0ull;
+            const uint32_t first_l = __builtin_amdgcn_readfirstlane((uint32_t)__ffsll((long long)rmask) - 1u);
+            const uint32_t last_l = __builtin_amdgcn_readfirstlane(63u - (uint32_t)__clzll((long long)rmask));
+            const uint32_t lo_first = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)lo_mine, (int)first_l);
+            const uint32_t k_last = (uint32_t)__builtin_amdgcn_readlane((int)kk, (int)last_l);
+            const uint32_t R = k_last - lo_first + 1u;  // rows to write (k-mer ids fit 32 bits)
+            if (R <= COOP_MAX_ROWS) {
+                coop = true;
+                uint32_t *const bits = s_rbits[w], *const pre = s_rpre[w];
+                u64 *const outs = s_rout[w];
+                bits[lane] = 0u;
+                if (rh) {
+                    const uint32_t off = kk - lo_first;
+                    atomicOr(&bits[off >> 5], 1u << (off & 31u));
+                    outs[(uint32_t)__popcll(rmask & lanes_below(lane))] =
+                        out0 + run + (uint32_t)__popcll(hm[j] & lanes_below(lane));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: the LDS keeps its operations in order)
+                const uint32_t wbits = bits[lane];
+                const uint32_t pc = (uint32_t)__popc(wbits);
+                pre[lane] = wave_incl_scan(pc) - pc;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (uint32_t r = lane; r < R; r += 64u) {
+                    const uint32_t below = pre[r >> 5] + (uint32_t)__popc(bits[r >> 5] & ((1u << (r & 31u)) - 1u));
+                    row_ind[(uint64_t)lo_first + r] = outs[below];  // the first head at or after row r
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next round overwrites the three arrays
+            }
+        }
         if ((hm[j] >> lane) & 1ull) {
             const u64 above = (lane == 63) ? 0ull : (hm[j] >> (lane + 1));
             const uint32_t nxt = above ? i + (uint32_t)__ffsll((long long)above) : nxt_after[j];
@@ -1565,7 +1611,7 @@ __global__ __launch_bounds__(RNT, 4) void k_rle(const ET *ent, uint32_t *scal, u
             const bool row_head = (rm[j] >> lane) & 1ull, last_head = nxt == E;
             if (row_head || last_head) {  // rare: at most M + 1 lanes of the whole launch
                 const uint32_t k = key_of(i, e[j]);
-                if (row_head) {
+                if (row_head && !coop) {
                     const uint64_t lo = (i == 0) ? 0ull : (uint64_t)key_of(i - 1, prev) + 1;
                     fill_rows(row_ind, lo, (uint64_t)k + 1, o, tasks, p_ntasks, task_cap, p_err);
                 }
