@@ -97,6 +97,8 @@ def handle():
     lib.kmers_csr_merge.argtypes = [C.c_int, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp, vp]
     lib.kmers_csr_place.restype = C.c_int
     lib.kmers_csr_place.argtypes = [C.c_uint64, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.kmers_csr_place_rows.restype = C.c_int
+    lib.kmers_csr_place_rows.argtypes = [C.c_uint64, vp, vp, vp, vp, vp, vp, vp]
     lib.kmers_npz_write_csr.restype = C.c_int
     lib.kmers_npz_write_csr.argtypes = [C.c_char_p, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64]
     lib.kmers_hip_model_create.restype = C.c_int

@@ -540,4 +540,16 @@ int kmers_csr_place(uint64_t n_rows, const uint64_t *row_ind, const uint64_t *be
     return KMERS_OK;
 }
 
+int kmers_csr_place_rows(uint64_t n, const uint64_t *src_start, const uint32_t *len, const uint64_t *dst_start, const float *data,
+                         const uint64_t *col_ind, float *out_data, uint64_t *out_col_ind) {
+    if (n && (!src_start || !len || !dst_start || !data || !col_ind || !out_data || !out_col_ind)) return KMERS_ERR_BAD_ARG;
+    kmers::parallel_for((size_t)n, 1u << 14, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            memcpy(out_col_ind + dst_start[i], col_ind + src_start[i], (size_t)len[i] * 8);
+            memcpy(out_data + dst_start[i], data + src_start[i], (size_t)len[i] * 4);
+        }
+    });
+    return KMERS_OK;
+}
+
 }  // extern "C"

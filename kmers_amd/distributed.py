@@ -128,7 +128,8 @@ def concat_x_shards(data, col_ind, row_ind, nnz, n_rows, gloo=False):
       * rank g's entries of row r go to  global[r] + (entries of row r on ranks < g), an exclusive prefix over the
         ranks of the same vector (_rank_prefix);
       * every rank copies its shard to the host over its own PCIe link and writes its rows in place in one POSIX
-        shared-memory CSR (kmers_csr_place, all host threads), so the copies and the placement run on all ranks at once."""
+        shared-memory CSR (kmers_csr_place_rows, all host threads), so the copies and the placement run on all ranks at
+        once."""
     import torch
     dist = _dist()
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -165,12 +166,19 @@ def concat_x_shards(data, col_ind, row_ind, nnz, n_rows, gloo=False):
 
     err = None
     try:
-        # destination of this rank's row r = global start of the row + the row's entries on the ranks in front: formed where
-        # the vectors are (on the GPU with RCCL), so only two row vectors cross PCIe (three on rank 0, which keeps the pointer)
-        dst = glob[:-1] + (before[1:] - before[:-1])
-        del before
+        # destination of this rank's row r = global start of the row + the row's entries on the ranks in front.  Formed
+        # where the vectors are (on the GPU with RCCL) and only for the rows this rank has entries in -- a column shard at
+        # K = 14 fills a sixth of its 2^28 rows --, so the list of (source start, length, destination) crosses PCIe, not
+        # the row vectors (rank 0 also takes the global pointer)
+        cnt = row_c[1:] - row_c[:-1]
+        rows = torch.nonzero(cnt).squeeze(1)
+        n_list = int(rows.numel())
+        src = row_c[:-1][rows]
+        dst = (glob[:-1] + (before[1:] - before[:-1]))[rows]
+        ln = cnt[rows].to(torch.int32)
+        del before, cnt
         h_data, h_col = to_host(data, nnz), to_host(col_ind, nnz)
-        h_row, h_dst = to_host(row_ind, n_rows + 1), to_host(dst, n_rows)
+        h_src, h_dst, h_len = to_host(src, n_list), to_host(dst, n_list), to_host(ln, n_list)
         h_glob = to_host(glob, n_rows + 1) if rank == 0 else None
         if row_ind.is_cuda:
             torch.cuda.synchronize()
@@ -211,9 +219,9 @@ def concat_x_shards(data, col_ind, row_ind, nnz, n_rows, gloo=False):
     try:
         o_data, o_col, o_row = (np.memmap(base[0] + ".%d" % i, dtype=dt, mode="r+", shape=(n,))
                                 for i, (n, dt) in enumerate(shapes))
-        rc = lib.kmers_csr_place(n_rows, h_row.ctypes.data, None, h_dst.ctypes.data, h_data.ctypes.data, h_col.ctypes.data,
-                                 o_data.ctypes.data, o_col.ctypes.data, None)
-        _lib.check(rc, "kmers_csr_place")
+        rc = lib.kmers_csr_place_rows(n_list, h_src.ctypes.data, h_len.ctypes.data, h_dst.ctypes.data, h_data.ctypes.data,
+                                      h_col.ctypes.data, o_data.ctypes.data, o_col.ctypes.data)
+        _lib.check(rc, "kmers_csr_place_rows")
         if rank == 0:
             o_row[:] = h_glob.view(np.uint64)
             out = (o_data[:total], o_row, o_col[:total])
