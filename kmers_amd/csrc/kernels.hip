@@ -1554,8 +1554,9 @@ __global__ __launch_bounds__(RNT, 4) void k_rle(const ET *ent, uint32_t *scal, u
             const uint32_t last_l = __builtin_amdgcn_readfirstlane(63u - (uint32_t)__clzll((long long)rmask));
             const uint32_t lo_first = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)lo_mine, (int)first_l);
             const uint32_t k_last = (uint32_t)__builtin_amdgcn_readlane((int)kk, (int)last_l);
-            const uint32_t R = k_last - lo_first + 1u;  // rows to write (k-mer ids fit 32 bits)
-            if (R <= COOP_MAX_ROWS) {
+            const uint64_t R64 = (uint64_t)k_last - lo_first + 1ull;  // rows to write (all 2^32 of them at K = 16, in principle)
+            if (R64 <= COOP_MAX_ROWS) {
+                const uint32_t R = (uint32_t)R64;
                 coop = true;
                 uint32_t *const bits = s_rbits[w], *const pre = s_rpre[w];
                 u64 *const outs = s_rout[w];

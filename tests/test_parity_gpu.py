@@ -58,6 +58,19 @@ def test_x_wide_entries_for_small_k(product, oracle, syn, K, monkeypatch):
     kmtest.assert_x_equal(product.x([syn["iso"], syn["uni"]], K), oracle.x([syn["iso"], syn["uni"]], K))
 
 
+@pytest.mark.parametrize("K", [9, 12, 16])
+def test_x_first_and_last_row_in_one_round(product, oracle, tmp_path, K):
+    """A handful of distinct k-mers that include the smallest and the largest id (poly-A, poly-T): the row heads of ONE
+    64-entry round of k_rle span all 4^K rows (2^32 at K=16: the row count of the round does not fit 32 bits), and
+    long gaps lie between them."""
+    p = tmp_path / "span.fsa"
+    rng = np.random.default_rng(K)
+    rnd = lambda n: bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n)).decode()
+    p.write_text(">a\n" + "A" * (K + 1) + "C\n>b\n" + "T" * (K + 2) + "\n>c\n" + rnd(K + 9) + "\n>d\n" + "G" * K + "\n>e\n"
+                 + "A" * K + "\n")
+    kmtest.assert_x_equal(product.x([str(p)], K), oracle.x([str(p)], K))
+
+
 @pytest.mark.parametrize("K,L,cat", [(8, 0, False), (13, 900, False), (6, 0, True), (11, 2000, True)])
 def test_x_in_record_ranges_above_the_per_call_limit(product, oracle, syn, K, L, cat, monkeypatch):
     """An input of more positions than one device call indexes (2^32 - 65536) is built in contiguous record ranges that
