@@ -134,12 +134,6 @@ __device__ __forceinline__ uint32_t region_from(const uint32_t *sreg, uint32_t i
     while (sreg[r + 1] <= i) ++r;
     return r;
 }
-// regions[d] = tilebase[tile 0][d] of the scanned tile histogram; regions[256] = entry count
-__global__ void k_regions(const uint32_t *tilebase, uint32_t n_tiles, const uint32_t *p_count, uint32_t *regions) {
-    const uint32_t d = threadIdx.x;
-    if (d < RADIX) regions[d] = tilebase[d];
-    if (d == RADIX) regions[RADIX] = *p_count;
-}
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release/acquire fence around
 // s_barrier, and on gfx950 global loads, stores and LDS ops are released by s_waitcnt vmcnt(0) / lgkmcnt(0): it would
@@ -189,7 +183,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *stmp /
 struct BasesArgs {
     const uint32_t *bases;
     const uint32_t *valid;
-    const uint32_t *rec_flags;  // bit p set: a record starts at position p (built by k_mark_records); may be null (y)
+    const uint32_t *rec_flags;  // bit p set: a record starts at position p (built by k_record_tables); may be null (y)
     const uint32_t *tile_cb;    // [n_tiles + 1]: record starts strictly before tile t's first position
     uint64_t bases_words, valid_words;
     uint64_t n_pos;
@@ -307,17 +301,17 @@ __device__ __forceinline__ uint32_t rec_lanes_at(const RecLanes &r, int j, uint3
     return rec;
 }
 
-// bit p of rec_flags := a record starts at p.  rec_flags is zeroed beforehand.
-__global__ void k_mark_records(const uint64_t *rec_start, uint64_t n_rec, uint32_t *rec_flags) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rec) return;
-    const uint64_t p = rec_start[r];
-    atomicOr(&rec_flags[p >> 5], 1u << (p & 31));
-}
-
-// tile_cb[t] = number of records that start strictly before position t*TILE, t in [0, n_tiles].
-__global__ void k_tile_cb(const uint64_t *rec_start, uint64_t n_rec, uint32_t n_tiles, uint32_t *tile_cb) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// One launch for the two record tables.  Threads [0, n_rec): bit p of rec_flags := a record starts at p (rec_flags is
+// zeroed beforehand).  Threads [n_rec, n_rec + n_tiles]: tile_cb[t] = number of records that start strictly before
+// position t*TILE, t in [0, n_tiles].
+__global__ void k_record_tables(const uint64_t *rec_start, uint64_t n_rec, uint32_t *rec_flags, uint32_t n_tiles, uint32_t *tile_cb) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_rec) {
+        const uint64_t p = rec_start[g];
+        atomicOr(&rec_flags[p >> 5], 1u << (p & 31));
+        return;
+    }
+    const uint64_t t = g - n_rec;
     if (t > n_tiles) return;
     const uint64_t target = t * TILE;
     uint64_t lo = 0, hi = n_rec;  // first r with rec_start[r] >= target
@@ -1262,10 +1256,17 @@ __global__ __launch_bounds__(RADIX *CSCAN_SEG) void k_cscan_mid(uint32_t *chunk_
     }
 }
 
-__global__ __launch_bounds__(RADIX) void k_cscan_apply(uint32_t *hist, uint32_t n_tiles, const uint32_t *chunk_base) {
+// regions (may be null): regions[d] = position of the first entry of digit d = tile 0's scanned row, regions[256] = the
+// entry count *p_count (no launch of its own).
+__global__ __launch_bounds__(RADIX) void k_cscan_apply(uint32_t *hist, uint32_t n_tiles, const uint32_t *chunk_base, uint32_t *regions,
+                                                       const uint32_t *p_count) {
     const uint32_t d = threadIdx.x, c = blockIdx.x;
     const uint32_t t0 = c * CSCAN_TILES, t1 = (t0 + CSCAN_TILES < n_tiles) ? t0 + CSCAN_TILES : n_tiles;
     uint32_t run = chunk_base[(uint64_t)c * RADIX + d];
+    if (regions && c == 0) {
+        regions[d] = run;
+        if (d == 0) regions[RADIX] = *p_count;
+    }
 #pragma unroll 8
     for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t v = hist[(uint64_t)t * RADIX + d];
@@ -2495,11 +2496,12 @@ size_t x_workspace_bytes(uint64_t n_pos, uint64_t n_rec, int K) { return x_layou
     } while (0)
 
 // hist[n_tiles][RADIX] -> bases in place; *p_total = number of entries.  chunk_sums: cscan_chunks(n_tiles) * RADIX words.
-static int scan_tilehist(uint32_t *hist, uint32_t n_tiles, uint32_t *chunk_sums, uint32_t *p_total, hipStream_t s) {
+static int scan_tilehist(uint32_t *hist, uint32_t n_tiles, uint32_t *chunk_sums, uint32_t *p_total, hipStream_t s,
+                         uint32_t *regions = nullptr, const uint32_t *p_count = nullptr) {
     const uint32_t nc = cscan_chunks(n_tiles);
     hipLaunchKernelGGL(k_cscan_reduce, dim3(nc), dim3(RADIX), 0, s, (const uint32_t *)hist, n_tiles, chunk_sums);
     hipLaunchKernelGGL(k_cscan_mid, dim3(1), dim3(RADIX * CSCAN_SEG), 0, s, chunk_sums, nc, p_total);
-    hipLaunchKernelGGL(k_cscan_apply, dim3(nc), dim3(RADIX), 0, s, hist, n_tiles, (const uint32_t *)chunk_sums);
+    hipLaunchKernelGGL(k_cscan_apply, dim3(nc), dim3(RADIX), 0, s, hist, n_tiles, (const uint32_t *)chunk_sums, regions, p_count);
     KK_CHECK(hipGetLastError());
     return 0;
 }
@@ -2674,9 +2676,8 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         const uint32_t nt0 = (nt + 1) / 2;
         hipLaunchKernelGGL(k_hist_words_y<1024>, dim3(nt0 < (uint32_t)HW_BLOCKS ? nt0 : (uint32_t)HW_BLOCKS), dim3(1024), 0, s, a, hist, n_words8, nt0);
         pt.mark("k_hist_words_y");
-        if (int rc = scan_tilehist(hist, nt0, bsum, &scal[0], s)) return rc;
+        if (int rc = scan_tilehist(hist, nt0, bsum, &scal[0], s, regs0, c_E)) return rc;
         pt.mark("k_scan");
-        hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, nt0, c_E, regs0);
         if (two_pass)
             hipLaunchKernelGGL((k_yscatter<uint32_t, 1024>), dim3(nt0 < (uint32_t)YS32_BLOCKS ? nt0 : (uint32_t)YS32_BLOCKS), dim3(1024), 0, s, a, c_hist, n_words8, nt0, entA);
         else  // one pass: 2-byte payloads
@@ -2686,9 +2687,8 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         if (two_pass) {
             hipLaunchKernelGGL(k_hist_entries<uint32_t>, hgrid, block, 0, s, (const uint32_t *)entA, c_E, 8, hist, nt);
             pt.mark("k_hist_entries");
-            if (int rc = scan_tilehist(hist, nt, bsum, &scal[4], s)) return rc;
+            if (int rc = scan_tilehist(hist, nt, bsum, &scal[4], s, regs1, c_E)) return rc;
             pt.mark("k_scan");
-            hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, nt, c_E, regs1);
             // this pass keeps the order of the byte pass 0 sorted on (k_count_y_sorted searches a region by it): mode 2
             hipLaunchKernelGGL((k_scatter<false, uint32_t, 2>), pgrid, block, 0, s, a, (const uint32_t *)entA, c_E, 8, c_hist, nt, entB,
                                (const uint32_t *)regs0);
@@ -2746,9 +2746,8 @@ static int build_x_tables(const XLayout &l, const uint32_t *d_bases, size_t base
     hipLaunchKernelGGL(k_dd<false>, dim3(DD_GRID), dim3(DD_NT), 0, s, a, hist, total, (uint32_t *)nullptr, colbits,
                        (DDEscape *)nullptr, 0u, scal);
     pt.mark("k_dd<hist>");
-    if (int rc = scan_tilehist(hist, rows, bsum, &scal[0], s)) return rc;
+    if (int rc = scan_tilehist(hist, rows, bsum, &scal[0], s, regs0, (const uint32_t *)&scal[0])) return rc;
     pt.mark("k_scan");
-    hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, (const uint32_t *)hist, rows, (const uint32_t *)&scal[0], regs0);
     hipLaunchKernelGGL(k_dd<true>, dim3(DD_GRID), dim3(DD_NT), 0, s, a, hist, total, entA, colbits, esc, l.esc_cap, scal);
     pt.mark("k_dd<scatter>");
     const uint32_t nt1 = l.n_tiles + 1;  // one tile beyond the entries: an all-zero last row for k_row_counts
@@ -2826,10 +2825,10 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         }
     }
     const size_t flag_words = (size_t)((n_pos + 31) / 32 + 4);
-    KK_CHECK(hipMemsetAsync(flags, 0, flag_words * 4, s));
-    KK_CHECK(hipMemsetAsync(status, 0, ((size_t)l.n_tiles + 1) * 8, s));
-    hipLaunchKernelGGL(k_mark_records, dim3((uint32_t)((n_rec + 255) / 256)), dim3(256), 0, s, d_rec_start, n_rec, flags);
-    hipLaunchKernelGGL(k_tile_cb, dim3((l.n_tiles + 1 + 255) / 256), dim3(256), 0, s, d_rec_start, n_rec, l.n_tiles, tilecb);
+    // flags, tile_cb and status lie one after the other in the layout: one memset (tile_cb is written right after)
+    KK_CHECK(hipMemsetAsync(flags, 0, (l.off_status - l.off_flags) + ((size_t)l.n_tiles + 1) * 8, s));
+    hipLaunchKernelGGL(k_record_tables, dim3((uint32_t)((n_rec + l.n_tiles + 1 + 255) / 256)), dim3(256), 0, s, d_rec_start, n_rec, flags,
+                       l.n_tiles, tilecb);
     pt.mark("setup");
 
     // rec_flags is indexed like valid[] (one bit per position), so it shares valid's word bound
@@ -2848,21 +2847,19 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     // pass 0: packed bases -> instances partitioned by the lowest digit
     hipLaunchKernelGGL(k_hist_bases, dim3(l.n_tiles < 4u * HB_BLOCKS ? (l.n_tiles + HB_NW - 1) / HB_NW : (uint32_t)HB_BLOCKS), dim3(HB_NT), 0, s, a, hist, l.n_tiles, total);
     pt.mark("k_hist_bases");
-    if (int rc = scan_tilehist(hist, l.n_tiles, bsum, &scal[0], s)) return rc;
+    if (int rc = scan_tilehist(hist, l.n_tiles, bsum, &scal[0], s, regs0, c_E)) return rc;
     pt.mark("k_scan");
     const uint32_t *final_regions = regs0;
     if (narrow) {
         uint32_t *ei = (uint32_t *)entA, *eo = (uint32_t *)entB;
-        hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, l.n_tiles, c_E, regs0);
         hipLaunchKernelGGL((k_scatter<true, uint32_t>), pgrid, block, 0, s, a, (const uint32_t *)nullptr, c_E, 0, c_hist, l.n_tiles,
                            ei, (const uint32_t *)nullptr);
         pt.mark("k_scatter<bases>");
         if (n_pass > 1) {
             hipLaunchKernelGGL(k_hist_entries<uint32_t>, hgrid, block, 0, s, (const uint32_t *)ei, c_E, 8, hist, l.n_tiles);
             pt.mark("k_hist_entries");
-            if (int rc = scan_tilehist(hist, l.n_tiles, bsum, &scal[4], s)) return rc;
+            if (int rc = scan_tilehist(hist, l.n_tiles, bsum, &scal[4], s, regs1, c_E)) return rc;
             pt.mark("k_scan");
-            hipLaunchKernelGGL(k_regions, dim3(1), dim3(512), 0, s, c_hist, l.n_tiles, c_E, regs1);
             hipLaunchKernelGGL((k_scatter<false, uint32_t>), pgrid, block, 0, s, a, (const uint32_t *)ei, c_E, 8, c_hist, l.n_tiles, eo,
                                (const uint32_t *)regs0);
             pt.mark("k_scatter<entries>");
