@@ -961,6 +961,165 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
     KK_STAMP_END(FROM_BASES ? 0 : 8);
 }
 
+// X pass 0, round 3: the order INSIDE one column does not matter.
+//
+// The later passes are stable and the run-length reduce only asks that the instances of one (k-mer, column) end up
+// adjacent and that, inside a row, the columns ascend.  Two instances of the SAME column that share the pass-0 digit are
+// told apart only by their higher digits, which the later (stable) passes sort on anyway, so pass 0 may leave them in any
+// order: what it has to keep is the order BETWEEN columns.  That removes the two things that made k_scatter<true> cost
+// 19 LDS instructions per 64 windows: the windows come out of registers (a thread shifts the 16 windows that start in
+// its packed word, as the y kernels do -- no LDS tile, no record lookup per window) and the rank inside (wave, digit) is
+// what ONE returning LDS atomic on the wave's own counter hands out.  The LDS runs a wave's instructions in order, so
+// all it takes to keep the columns apart is to issue the windows of one column before those of the next: a wave whose
+// 1024 positions hold no record start (two in three on a transcriptome) ranks in one sweep of 16 atomics, one with s
+// starts in s + 1 sweeps.  Waves stay ordered through their private counters (scan over the waves, as before).
+// Tiles are BNT * 16 positions = BNT / 512 rows of the (8192-position) tile histogram: in the scanned table the rows of
+// one digit follow each other, so the first row's base serves the whole tile.
+template <class ET, int BNT>
+__global__ __launch_bounds__(BNT) void k_xscatter0(BasesArgs a, const uint32_t *tilebase, uint32_t n_tiles8, ET *out) {
+    constexpr bool NARROW = sizeof(ET) == 4;
+    constexpr int BNW = BNT / 64, BTILE = BNT * 16, TPB = BTILE / TILE;
+    static_assert(BNT % NT == 0, "a tile is a whole number of histogram rows");
+    __shared__ __attribute__((aligned(16))) ET sent[BTILE];
+    __shared__ uint8_t saux[NARROW ? BTILE : 4];  // narrow: the digit of every staged entry (the entry holds the OTHER byte)
+    __shared__ uint32_t wcnt[BNW][RADIX];
+    __shared__ uint32_t gadj[RADIX], swave[BNW], sdig[RADIX / 64];
+    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
+    const uint32_t nbt = (n_tiles8 + TPB - 1) / TPB;
+    const uint32_t per = (nbt + gridDim.x - 1) / gridDim.x;
+    const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < nbt) ? t0 + per : nbt;
+    if (t0 >= t1) return;
+    const int K = a.K;
+    auto fetch_flags = [&](uint64_t g) -> uint32_t {  // record starts among positions 16 g .. 16 g + 15
+        const uint32_t fw = ((g >> 1) < a.valid_words) ? a.rec_flags[g >> 1] : 0u;
+        return (g & 1) ? (fw >> 16) : (fw & 0xFFFFu);
+    };
+    WordWindows nx = word_fetch(a, (uint64_t)t0 * BNT + tid);
+    uint32_t nfl = fetch_flags((uint64_t)t0 * BNT + tid);
+    uint32_t ncb = a.tile_cb[(uint64_t)t0 * TPB];
+    uint32_t gb = (tid < RADIX) ? tilebase[(uint64_t)t0 * TPB * RADIX + tid] : 0u;
+    uint32_t *const wrow = &wcnt[w][0];
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+        for (uint32_t i = tid; i < BNW * RADIX; i += BNT) (&wcnt[0][0])[i] = 0;
+        const WordWindows x = nx;
+        const uint32_t fl = nfl, cb_tile = ncb;
+        if (tile + 1 < t1) {
+            nx = word_fetch(a, (uint64_t)(tile + 1) * BNT + tid);
+            nfl = fetch_flags((uint64_t)(tile + 1) * BNT + tid);
+            ncb = a.tile_cb[(uint64_t)(tile + 1) * TPB];
+        }
+        // record starts before this thread's word: in the wave (-> sweeps), in the tile (-> column numbers)
+        const uint32_t nf = (uint32_t)__popc(fl);
+        const uint32_t finc = wave_incl_scan(nf);
+        const uint32_t wave_starts = (uint32_t)__builtin_amdgcn_readlane((int)finc, 63);
+        if (lane == 63) swave[w] = finc;
+        lds_sync();
+        uint32_t before_w = 0;
+#pragma unroll
+        for (int i = 0; i < BNW; ++i)
+            if ((uint32_t)i < w) before_w += swave[i];
+        const uint32_t lc0 = finc - nf;                 // starts in this wave's chunk before the word
+        const uint32_t col0 = cb_tile + before_w + lc0 - 1u;  // column of a position of this word that follows no start in it
+        const uint32_t okm = runs_of(x.v, K) & 0xFFFFu;   // bit j: window j of the word is a k-mer
+        uint32_t rank[16];  // bits 0..15 the rank inside (wave, digit), bits 16..23 the digit; NONE = no k-mer
+        auto digit_of = [&](int j) -> uint32_t {
+            const uint32_t top = j ? __builtin_amdgcn_alignbit(x.b0, x.b1, 32u - 2u * (uint32_t)j) : x.b0;
+            return (top >> (32u - 2u * (uint32_t)K)) & 255u;
+        };
+#ifdef XS0_NOPHASE  // diagnostic builds (wrong results)
+        if (true) {
+#else
+        if (wave_starts == 0) {  // (wave-uniform) one column: any order will do
+#endif
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                rank[j] = NONE;
+                if ((okm >> j) & 1u) {
+                    const uint32_t d = digit_of(j);
+                    rank[j] = atomicAdd(&wrow[d], 1u) | (d << 16);
+                }
+            }
+        } else {  // column after column (sweep ph takes the windows that follow exactly ph starts of the wave's chunk)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) rank[j] = NONE;
+            for (uint32_t ph = 0; ph <= wave_starts; ++ph) {
+                if (__ballot(ph >= lc0 && ph <= lc0 + nf) == 0ull) continue;  // no word of the wave reaches this column
+                // (opaque copies: otherwise the 16 digits and 16 start counts are hoisted out of the sweep loop and spill)
+                uint32_t b0 = x.b0, b1 = x.b1, flo = fl;
+                asm volatile("" : "+v"(b0), "+v"(b1), "+v"(flo));
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t lc = lc0 + (uint32_t)__popc(flo & ((2u << j) - 1u));
+                    if (((okm >> j) & 1u) && lc == ph) {
+                        const uint32_t top = j ? __builtin_amdgcn_alignbit(b0, b1, 32u - 2u * (uint32_t)j) : b0;
+                        const uint32_t d = (top >> (32u - 2u * (uint32_t)K)) & 255u;
+                        rank[j] = atomicAdd(&wrow[d], 1u) | (d << 16);
+                    }
+                }
+            }
+        }
+        lds_sync();
+        // digit d: exclusive scan of the per-wave counts over the waves, then of the tile totals over the digits
+        uint32_t dtot = 0;
+        if (tid < RADIX) {
+#pragma unroll
+            for (int i = 0; i < BNW; ++i) {
+                const uint32_t c = wcnt[i][tid];
+                wcnt[i][tid] = dtot;
+                dtot += c;
+            }
+        }
+        const uint32_t dinc = wave_incl_scan(dtot);
+        if (tid < RADIX && lane == 63) sdig[w] = dinc;
+        lds_sync();
+        uint32_t dbase = 0, tile_count = 0;
+#pragma unroll
+        for (int i = 0; i < RADIX / 64; ++i) {
+            const uint32_t t = sdig[i];
+            if ((uint32_t)i < w) dbase += t;
+            tile_count += t;
+        }
+        if (tid < RADIX) {
+            const uint32_t dstart = dbase + dinc - dtot;
+#pragma unroll
+            for (int i = 0; i < BNW; ++i) wcnt[i][tid] += dstart;
+            gadj[tid] = gb - dstart;
+            if (tile + 1 < t1) gb = tilebase[(uint64_t)(tile + 1) * TPB * RADIX + tid];
+        }
+        lds_sync();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (rank[j] != NONE) {
+                const uint32_t top = j ? __builtin_amdgcn_alignbit(x.b0, x.b1, 32u - 2u * (uint32_t)j) : x.b0;
+                const uint32_t key = top >> (32u - 2u * (uint32_t)K);
+                const uint32_t col = col0 + (uint32_t)__popc(fl & ((2u << j) - 1u));
+                const uint32_t d = (rank[j] >> 16) & 255u;
+                const uint32_t slot = wrow[d] + (rank[j] & 0xFFFFu);
+                if constexpr (NARROW) {
+                    sent[slot] = ((key >> 8) << 24) | col;
+                    saux[slot] = (uint8_t)d;
+                } else {
+                    sent[slot] = make_entry(key, col);
+                }
+            }
+        }
+        lds_sync();
+        for (uint32_t i = tid; i < tile_count; i += BNT) {
+            const ET v = sent[i];
+            uint32_t d;
+            if constexpr (NARROW)
+                d = saux[i];
+            else
+                d = entry_key((u64)v) & 255u;
+#ifdef XS0_NOSTORE  // diagnostic builds (wrong results)
+            if (v == (ET)0x12345678u)
+#endif
+            out[gadj[d] + i] = v;
+        }
+        lds_sync();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // y for K >= 9: histogram of partitioned k-mers
 // ------------------------------------------------------------------------------------------------------
@@ -1634,6 +1793,431 @@ __global__ __launch_bounds__(NT) void k_fill_tasks(uint64_t *row_ind, const Fill
     for (uint32_t t = blockIdx.x; t < n; t += gridDim.x) {
         const FillTask ft = tasks[t];
         for (uint64_t r = ft.begin + threadIdx.x; r < ft.end; r += NT) row_ind[r] = ft.value;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// X for K <= 8, round 3: the LAST partition pass writes the CSR arrays itself ("fused emit")
+// ------------------------------------------------------------------------------------------------------
+//
+// After pass 0 the 4-byte entries (high digit << 24 | column) lie in 256 regions (one per low digit d), each ordered by
+// column (in any order inside a column: k_xscatter0).  All instances of one (k-mer, column) are EQUAL 32-bit values
+// inside one contiguous (d, column) group.  The last pass partitions a tile of a region by the high digit h, stably:
+// in LDS the run of digit h then holds the tile's entries of row (h << 8 | d) with ascending columns and equal values
+// next to each other -- the CSR order -- so the run-length reduce happens where the entries already are, and the pass
+// stores `data` and `col_ind` instead of a sorted copy of the entries: k_scatter<entries>'s 1.6 GB of stores, k_rle's
+// 1.6 GB of loads, its scan across tiles and its launch are gone (config 2: 1.17 + 1.96 ms).
+//
+// What it takes:
+//  * the output position of the first non-zero of every (tile, h) must be known beforehand: k_heads_hist counts, per
+//    tile and h, the HEADS (first instance of an equal-value group, in region order), not the instances; the usual
+//    scan of that table gives the positions, nnz, and -- tiles never span two regions -- the row pointer itself:
+//    row_ind[h << 8 | d] = position of (first tile of region d, h).  No k_row_counts, no gap filling.
+//  * a group that straddles a tile boundary: the head is where the FIRST instance is.  A tile looks back over the
+//    entries in front of it that share its first column (sseen[h]: that (h, column) already has its head) and ahead over
+//    those behind it that share its last column (sextra[h]: instances to add to a head of this tile).  Both scans end
+//    with the column group, a dozen entries on a transcriptome; a group longer than SCAN_LIMIT probes (one record with
+//    millions of bases) raises scal[6] and the host redoes the build on the general path (k_scatter + k_rle).
+
+constexpr uint32_t FT = TILE;               // entries per tile of the fused passes
+constexpr uint32_t SCAN_LIMIT = 1u << 10;   // 64-entry probes one look-back / look-ahead may take
+
+// tstart[d] = number of tiles of the regions before d (region d has ceil(len / FT) tiles); tstart[256] = all tiles.
+__global__ __launch_bounds__(RADIX) void k_ftiles(const uint32_t *regions, uint32_t *tstart) {
+    __shared__ uint32_t sw[RADIX / 64];
+    const uint32_t d = threadIdx.x, lane = lane_id(), w = d >> 6;
+    const uint32_t n = (regions[d + 1] - regions[d] + FT - 1) / FT;
+    const uint32_t inc = wave_incl_scan(n);
+    if (lane == 63) sw[w] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t i = 0; i < w; ++i) base += sw[i];
+    tstart[d] = base + inc - n;
+    if (d == RADIX - 1) tstart[RADIX] = base + inc;
+}
+
+struct FTile {
+    uint32_t begin, end;     // entries of the tile
+    uint32_t rbegin, rend;   // its region
+    uint32_t d;
+};
+__device__ __forceinline__ FTile ftile_of(const uint32_t *s_ts, const uint32_t *s_reg, uint32_t tile) {
+    FTile f;
+    f.d = region_search(s_ts, tile);  // (empty regions share their tstart with the next one: the LARGEST d with tstart <= tile)
+    f.rbegin = s_reg[f.d];
+    f.rend = s_reg[f.d + 1];
+    f.begin = f.rbegin + (tile - s_ts[f.d]) * FT;
+    f.end = (f.rend - f.begin > FT) ? f.begin + FT : f.rend;
+    return f;
+}
+
+__device__ __forceinline__ uint32_t fe_col(uint32_t v) { return v & 0xFFFFFFu; }
+
+// previous lane's value (lane 0: undefined) without an LDS round trip: DPP wave_shr:1
+__device__ __forceinline__ uint32_t lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
+
+// Heads per (tile, h).  Every WAVE works alone on 1024 consecutive entries, 64 per round in entry order; T[h] = the column
+// in which an entry of digit h was last seen by this wave -- the region is ordered by column, so "T[h] == my column" says
+// that my value occurred before.  Inside a round the lanes of one value are found with the OR-mask match of the
+// partition kernels, restricted to the lanes of the same column (a contiguous stretch of lanes).  In front of its chunk a
+// wave first looks back over the entries that share its first column.
+__global__ __launch_bounds__(NT) void k_heads_hist(const uint32_t *ent, const uint32_t *regions, const uint32_t *tstart,
+                                                   uint32_t *tilehist, uint32_t rows, uint32_t *scal) {
+    __shared__ uint32_t s_reg[RADIX + 1], s_ts[RADIX + 1];
+    __shared__ uint32_t T[NW][RADIX];
+    __shared__ u64 wmask[NW][RADIX];
+    __shared__ uint32_t hist[2][RADIX];
+    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
+    for (uint32_t i = tid; i <= RADIX; i += NT) {
+        s_reg[i] = regions[i];
+        s_ts[i] = tstart[i];
+    }
+    for (uint32_t i = tid; i < NW * RADIX; i += NT) (&wmask[0][0])[i] = 0ull;
+    for (uint32_t i = tid; i < 2 * RADIX; i += NT) (&hist[0][0])[i] = 0u;
+    lds_sync();
+    const uint32_t n_ft = s_ts[RADIX];
+    const uint32_t per = (rows + gridDim.x - 1) / gridDim.x;
+    const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < rows) ? t0 + per : rows;
+    uint32_t *const Tw = T[w];
+    u64 *const mw = wmask[w];
+    uint32_t e[IPT], probe = 0;
+    FTile ft{0, 0, 0, 0, 0};
+    auto load_tile = [&](uint32_t t) {
+        if (t >= n_ft) return;  // (workgroup-uniform)
+        ft = ftile_of(s_ts, s_reg, t);
+        const uint32_t s0 = ft.begin + w * WCHUNK;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t i = s0 + j * 64 + lane;
+            e[j] = (i < ft.end) ? __builtin_nontemporal_load(&ent[i]) : 0u;
+        }
+        probe = (s0 < ft.end && s0 >= ft.rbegin + 1u + lane) ? ent[s0 - 1u - lane] : NONE;  // (NONE: no column is 2^24 - 1 ... see below)
+    };
+    if (t0 < t1) load_tile(t0);
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+        uint32_t *const hc = hist[(tile - t0) & 1u], *const hn = hist[((tile - t0) & 1u) ^ 1u];
+        if (tile >= n_ft) {  // rows past the last tile: zeros (the scan runs over all `rows`)
+            if (tid < RADIX) tilehist[(uint64_t)tile * RADIX + tid] = 0u;
+            continue;
+        }
+        const FTile f = ft;
+        const uint32_t s0 = f.begin + w * WCHUNK;
+#pragma unroll
+        for (int i = 0; i < RADIX / 64; ++i) Tw[lane + 64 * i] = NONE;
+        if (s0 < f.end && s0 > f.rbegin) {  // (wave-uniform) look back over the entries that share the chunk's first column
+            const uint32_t c0 = fe_col((uint32_t)__builtin_amdgcn_readfirstlane((int)e[0]));
+            uint32_t at = s0, it = 0;  // the probe holds entries at - 1 - lane
+            for (;;) {
+                const bool in = at >= f.rbegin + 1u + lane;
+                const bool same = in && fe_col(probe) == c0;
+                const u64 stop = __ballot(!same);
+                const uint32_t n_same = stop ? (uint32_t)__ffsll((long long)stop) - 1u : 64u;
+                if (lane < n_same) Tw[probe >> 24] = c0;
+                if (stop) break;
+                if (++it > SCAN_LIMIT) {
+                    if (lane == 0) scal[6] = 1u;
+                    break;
+                }
+                at -= 64u;
+                probe = (at >= f.rbegin + 1u + lane) ? ent[at - 1u - lane] : NONE;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t i = s0 + j * 64 + lane;
+            const bool ok = i < f.end;
+            const uint32_t v = e[j], h = v >> 24, c = fe_col(v);
+            // lanes of my column in this round: from the last column change at or below me
+            const uint32_t pc = lane_prev(c);
+            const u64 chg = __ballot(lane == 0 || pc != c);
+            const u64 upto = chg & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+            const uint32_t seg0 = 63u - (uint32_t)__clzll((long long)upto);  // (bit 0 is always set)
+            u64 m = 0;
+            uint32_t t = NONE;
+            if (ok) {
+                atomicOr(&mw[h], 1ull << lane);
+                m = mw[h];
+                t = Tw[h];
+            }
+            const u64 mine = m & lanes_below(lane) & ~lanes_below(seg0);  // lower lanes with my value
+            const bool head = ok && mine == 0ull && t != c;
+            if (ok && (lane == 63 || (m >> (lane + 1)) == 0ull)) {  // the last lane of digit h in this round
+                Tw[h] = c;
+                mw[h] = 0ull;
+            }
+            if (head) atomicAdd(&hc[h], 1u);
+            asm volatile("" ::: "memory");
+        }
+        if (tile + 1 < t1) load_tile(tile + 1);
+        if (tid < RADIX) hn[tid] = 0u;  // the other table, for the next tile
+        lds_sync();
+        if (tid < RADIX) tilehist[(uint64_t)tile * RADIX + tid] = hc[tid];
+        lds_sync();  // the next tile's atomics go to hn; hc is zeroed a tile later, after these reads
+    }
+}
+
+// row_ind from the scanned head table (see above); scal[1] = nnz.
+__global__ void k_row_ptr_fused(const uint32_t *headbase, const uint32_t *tstart, const uint32_t *p_nnz, uint64_t M,
+                                uint64_t *row_ind, uint32_t *scal) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > M) return;
+    if (r == M) {
+        row_ind[M] = *p_nnz;
+        scal[1] = *p_nnz;
+        return;
+    }
+    const uint32_t h = (uint32_t)(r >> 8), d = (uint32_t)r & 255u;
+    row_ind[r] = headbase[(uint64_t)tstart[d] * RADIX + h];
+}
+
+// The last pass: stable partition of a tile by h in LDS, then every wave turns a contiguous eighth of the partitioned
+// tile into CSR entries.
+__global__ __launch_bounds__(NT, 4) void k_emit(const uint32_t *ent, const uint32_t *regions, const uint32_t *tstart,
+                                                const uint32_t *headbase, const uint32_t *rec_total, uint64_t first_col,
+                                                uint64_t max_nz, float *data, uint64_t *col_ind, uint32_t *scal) {
+    __shared__ __attribute__((aligned(16))) uint32_t stage[FT];  // the partitioned tile; first the match masks
+    __shared__ uint32_t wcnt[NW][RADIX];
+    __shared__ uint32_t s_reg[RADIX + 1], s_ts[RADIX + 1];
+    __shared__ uint32_t sseen[RADIX], sextra[RADIX], shb[RADIX];
+    __shared__ uint32_t sadj_all[NW][RADIX];  // per wave: see the emit loop
+    __shared__ uint32_t stmp[NW], s_c[2];
+    static_assert(NW * RADIX * 8 <= FT * 4, "match masks alias the entry staging");
+    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
+    for (uint32_t i = tid; i <= RADIX; i += NT) {
+        s_reg[i] = regions[i];
+        s_ts[i] = tstart[i];
+    }
+    lds_sync();
+    const uint32_t n_ft = s_ts[RADIX];
+    const uint32_t per = (n_ft + gridDim.x - 1) / gridDim.x;
+    const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < n_ft) ? t0 + per : n_ft;
+    if (t0 >= t1) return;
+    u64 *const smask = reinterpret_cast<u64 *>(stage);
+    uint32_t *const sadj = sadj_all[w];
+    uint32_t e[IPT], probe = NONE;
+    FTile ft{0, 0, 0, 0, 0};
+    auto load_tile = [&](uint32_t t) {
+        ft = ftile_of(s_ts, s_reg, t);
+        const uint32_t s0 = ft.begin + w * WCHUNK;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint32_t i = s0 + j * 64 + lane;
+            e[j] = (i < ft.end) ? ent[i] : 0u;
+        }
+        probe = NONE;
+        if (w == 0 && ft.begin >= ft.rbegin + 1u + lane) probe = ent[ft.begin - 1u - lane];       // look back
+        if (w == NW - 1 && ft.end + lane < ft.rend) probe = ent[ft.end + lane];                    // look ahead
+    };
+    load_tile(t0);
+    uint32_t gb = (tid < RADIX) ? headbase[(uint64_t)t0 * RADIX + tid] : 0u;
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+        const FTile f = ft;
+        const uint32_t n = f.end - f.begin;  // entries of the tile (>= 1)
+        for (uint32_t i = tid; i < NW * RADIX; i += NT) {
+            (&wcnt[0][0])[i] = 0;
+            smask[i] = 0ull;
+        }
+        if (tid < RADIX) {
+            sseen[tid] = 0u;
+            sextra[tid] = 0u;
+            shb[tid] = gb;
+            if (tile + 1 < t1) gb = headbase[(uint64_t)(tile + 1) * RADIX + tid];
+        }
+        lds_sync();
+        // ---- the neighbours of the tile inside its region (waves 0 and NW - 1, while the others rank)
+        if (w == 0) {
+            uint32_t c0 = NONE;
+            if (f.begin > f.rbegin) {
+                c0 = fe_col((uint32_t)__builtin_amdgcn_readfirstlane((int)e[0]));
+                uint32_t at = f.begin, it = 0;
+                bool any = false;
+                for (;;) {
+                    const bool same = at >= f.rbegin + 1u + lane && fe_col(probe) == c0;
+                    const u64 stop = __ballot(!same);
+                    const uint32_t n_same = stop ? (uint32_t)__ffsll((long long)stop) - 1u : 64u;
+                    if (lane < n_same) sseen[probe >> 24] = 1u;
+                    any = any || n_same;
+                    if (stop) break;
+                    if (++it > SCAN_LIMIT) {
+                        if (lane == 0) scal[6] = 1u;
+                        break;
+                    }
+                    at -= 64u;
+                    probe = (at >= f.rbegin + 1u + lane) ? ent[at - 1u - lane] : NONE;
+                }
+                if (!any) c0 = NONE;  // nothing in front shares the first column: no lane needs to ask
+            }
+            if (lane == 0) s_c[0] = c0;
+        }
+        if (w == NW - 1) {
+            uint32_t c1 = NONE;
+            if (f.end < f.rend) {  // (then the tile is full: its last entry is this wave's last)
+                c1 = fe_col((uint32_t)__builtin_amdgcn_readlane((int)e[IPT - 1], 63));
+                uint32_t at = f.end, it = 0;
+                bool any = false;
+                for (;;) {
+                    const bool same = at + lane < f.rend && fe_col(probe) == c1;
+                    const u64 stop = __ballot(!same);
+                    const uint32_t n_same = stop ? (uint32_t)__ffsll((long long)stop) - 1u : 64u;
+                    if (lane < n_same) atomicAdd(&sextra[probe >> 24], 1u);
+                    any = any || n_same;
+                    if (stop) break;
+                    if (++it > SCAN_LIMIT) {
+                        if (lane == 0) scal[6] = 1u;
+                        break;
+                    }
+                    at += 64u;
+                    probe = (at + lane < f.rend) ? ent[at + lane] : NONE;
+                }
+                if (!any) c1 = NONE;
+            }
+            if (lane == 0) s_c[1] = c1;
+        }
+        // ---- stable ranks inside (wave, h): the OR-mask match of k_scatter
+        uint32_t wl = w * WCHUNK + lane;
+        asm volatile("" : "+v"(wl));
+        uint32_t *const wrow = &wcnt[w][0];
+        u64 *const wmask = &smask[w * RADIX];
+        uint32_t rank[IPT];
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const bool ok = wl + j * 64 < n;
+            const uint32_t d = e[j] >> 24;
+            u64 m = 0;
+            uint32_t before = 0;
+            if (ok) {
+                atomicOr(&wmask[d], 1ull << lane);
+                m = wmask[d];
+                before = wrow[d];
+            }
+            const uint32_t m_lo = (uint32_t)m, m_hi = (uint32_t)(m >> 32);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+            rank[j] = ok ? (before + below) : NONE;
+            if (ok && below == 0) {
+                wrow[d] = before + (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);
+                wmask[d] = 0ull;
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_sync();
+        uint32_t dtot = 0;
+        uint32_t wc[NW];
+        if (tid < RADIX) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                wc[i] = dtot;
+                dtot += wcnt[i][tid];
+            }
+        }
+        uint32_t tile_count;
+        const uint32_t dstart = block_excl_scan<true>(dtot, stmp, tile_count);
+        if (tid < RADIX) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) wcnt[i][tid] = dstart + wc[i];
+        }
+        lds_sync();
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            if (rank[j] != NONE) stage[wrow[e[j] >> 24] + rank[j]] = e[j];
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tile + 1 < t1) load_tile(tile + 1);
+        lds_sync();
+        const uint32_t c0 = s_c[0], c1 = s_c[1];
+        // ---- emit: wave w owns stage[a, b); v[k] = stage[a + 64 k + lane]
+        const uint32_t a = w * WCHUNK;
+        if (a < n) {
+            const uint32_t b = (a + WCHUNK < n) ? a + WCHUNK : n;
+            uint32_t v[IPT];
+            u64 fm[IPT], hm[IPT];  // group firsts / heads (wave-uniform masks)
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                const uint32_t i = a + k * 64 + lane;
+                const bool in = i < b;
+                uint32_t x = 0, p = 0;
+                if (in) {
+                    x = stage[i];
+                    p = (i > 0) ? stage[i - 1] : ~x;
+                }
+                v[k] = x;
+                const bool first = in && x != p;
+                bool head = first;
+                if (first && fe_col(x) == c0) head = sseen[x >> 24] == 0u;  // (rare: the tile's first column)
+                fm[k] = __ballot(first);
+                hm[k] = __ballot(head);
+            }
+            // first group-first at or after b (the last group of the chunk ends there); n if none
+            uint32_t after = n;
+            {
+                const uint32_t last = stage[b - 1];
+                for (uint32_t q = b; q < n; q += 64) {
+                    const uint32_t i = q + lane;
+                    const u64 dm = __ballot(i < n && stage[i] != last);
+                    if (dm) {
+                        after = q + (uint32_t)__ffsll((long long)dm) - 1u;
+                        break;
+                    }
+                }
+            }
+            // heads of the chunk's first digit that lie in front of the chunk (its run may start in an earlier wave's part)
+            const uint32_t h_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[0]) >> 24;
+            uint32_t run = 0;  // heads of digit h_first in stage[dstart(h_first), a)
+            {
+                const uint32_t ds = wcnt[0][h_first];
+                for (uint32_t q = ds; q < a; q += 64) {
+                    const uint32_t i = q + lane;
+                    bool head = false;
+                    if (i < a) {
+                        const uint32_t x = stage[i], p = (i > 0) ? stage[i - 1] : ~x;
+                        head = x != p;
+                        if (head && fe_col(x) == c0) head = sseen[x >> 24] == 0u;
+                    }
+                    run += (uint32_t)__popcll(__ballot(head));
+                }
+            }
+            // sadj[h] (this wave's own table) = output position of digit h's first head minus the number of heads of THIS
+            // CHUNK in front of the digit's run, so that a head's position is sadj[h] + (heads of the chunk in front of it).
+            // Set by the lane that holds the first entry of the run; for a run that began in front of the chunk, here.
+            if (lane == 0) sadj[h_first] = shb[h_first] + run;
+            uint32_t nxt_after[IPT];
+            {
+                uint32_t nh = after;
+#pragma unroll
+                for (int k = IPT - 1; k >= 0; --k) {
+                    nxt_after[k] = nh;
+                    if (fm[k]) nh = a + k * 64 + (uint32_t)__ffsll((long long)fm[k]) - 1u;
+                }
+            }
+            uint32_t cnt_heads = 0;  // heads of the chunk in front of round k
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                if (fm[k] == 0ull) continue;  // (wave-uniform) a round inside one long group
+                const uint32_t i = a + k * 64 + lane;
+                const uint32_t x = v[k], h = x >> 24;
+                const bool is_first = (fm[k] >> lane) & 1ull, is_head = (hm[k] >> lane) & 1ull;
+                const uint32_t hr = cnt_heads + (uint32_t)__popcll(hm[k] & lanes_below(lane));  // heads of the chunk in front of me
+                // a digit's run starts at i (the chunk's first entry was dealt with above)
+                if (is_first && i > a && (stage[i - 1] >> 24) != h) sadj[h] = shb[h] - hr;
+                if (is_head) {
+                    const u64 above = (lane == 63) ? 0ull : (fm[k] >> (lane + 1));
+                    const uint32_t nxt = above ? i + (uint32_t)__ffsll((long long)above) : nxt_after[k];
+                    uint32_t cnt = nxt - i;
+                    const uint32_t c = fe_col(x);
+                    if (c == c1) cnt += sextra[h];  // (rare) the group goes on behind the tile
+                    const uint64_t o = (uint64_t)sadj[h] + hr;
+                    if (o < max_nz) {
+                        // reference: float(count) / total_count with total_count uint32_t: both operands are rounded to
+                        // float, then one IEEE float division (hipcc's default float division is correctly rounded)
+                        const uint32_t total = rec_total[c];
+                        data[o] = (float)cnt / (float)total;
+                        col_ind[o] = first_col + c;
+                    }
+                }
+                cnt_heads += (uint32_t)__popcll(hm[k]);
+            }
+        }
+        lds_sync();
     }
 }
 
@@ -2450,7 +3034,10 @@ static XLayout x_layout(uint64_t n_pos, uint64_t n_rec, int K) {
     const uint64_t emax = n_pos ? n_pos : 1;
     l.n_tiles = (uint32_t)((emax + TILE - 1) / TILE);
     l.dd_rows = (uint32_t)((emax + DD_C - 1) / DD_C) + DD_GRID + 2;
-    const uint32_t rows = (l.n_tiles + 1 > l.dd_rows) ? l.n_tiles + 1 : l.dd_rows;
+    // rows of the tile histogram: the partition's tiles (+ 1), the fused emit's region-aligned tiles (at most 256 more, + the
+    // all-zero rows behind them), the small-K table path's
+    uint32_t rows = l.n_tiles + RADIX + 2;
+    if (l.dd_rows > rows) rows = l.dd_rows;
     l.hist_len = (uint64_t)RADIX * rows;
     l.scan_blocks = cscan_chunks(rows);
     l.esc_cap = (uint32_t)(emax < (1u << 22) ? emax : (1u << 22));
@@ -2475,7 +3062,7 @@ static XLayout x_layout(uint64_t n_pos, uint64_t n_rec, int K) {
     l.off_tilecb = take(((size_t)l.n_tiles + 2) * 4);
     l.off_status = take(((size_t)l.n_tiles + 1) * 8);
     l.off_scalars = take(64);
-    l.off_regions = take(2 * (RADIX + 1) * 4);
+    l.off_regions = take(3 * (RADIX + 1) * 4);  // regions of two passes, tile starts of the fused emit
     l.off_tasks = take((size_t)l.task_cap * sizeof(FillTask));
     l.off_wgrec = take((DD_GRID + 1) * 4);
     l.off_esc = take((size_t)l.esc_cap * sizeof(DDEscape));
@@ -2783,6 +3370,20 @@ static int build_x_tables(const XLayout &l, const uint32_t *d_bases, size_t base
     return 0;
 }
 
+#ifndef XS0_NT_NARROW
+#define XS0_NT_NARROW 512
+#endif
+#ifndef XS0_NT_WIDE
+#define XS0_NT_WIDE 512
+#endif
+#ifndef XS0_BLOCKS
+#define XS0_BLOCKS 4096
+#endif
+static dim3 xs0_grid(uint32_t n_tiles8, int bnt) {
+    const uint32_t nbt = (n_tiles8 + (uint32_t)(bnt / NT) - 1) / (uint32_t)(bnt / NT);
+    return dim3(nbt < (uint32_t)XS0_BLOCKS ? nbt : (uint32_t)XS0_BLOCKS);
+}
+
 int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words, const uint64_t *d_rec_start,
             uint64_t n_pos, uint64_t n_rec, uint64_t first_col, int K, float *d_data, uint64_t *d_col_ind, uint64_t *d_row_ind,
             uint64_t max_nz, void *d_ws, size_t ws_bytes, uint64_t *nnz_out, hipStream_t s) {
@@ -2838,6 +3439,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     const dim3 pgrid(l.n_tiles < (uint32_t)PERSIST_BLOCKS ? l.n_tiles : (uint32_t)PERSIST_BLOCKS);
     const dim3 hgrid(l.n_tiles < (uint32_t)KK_HIST_BLOCKS ? l.n_tiles : (uint32_t)KK_HIST_BLOCKS);
     const int n_pass = (2 * K + 7) / 8;
+    const bool old_pass0 = getenv("KMERS_X_OLD_PASS0") != nullptr;  // env: A-B runs against the position-ordered pass 0
 
     // K <= 8 and at most 2^24 records: 4-byte entries (digit byte << 24 | column), else 8-byte (k-mer id << 32 | column)
     const bool narrow = (K <= 8) && (n_rec <= (1ull << 24)) && !getenv("KMERS_FORCE_WIDE");  // env: tests / A-B runs
@@ -2852,9 +3454,44 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     const uint32_t *final_regions = regs0;
     if (narrow) {
         uint32_t *ei = (uint32_t *)entA, *eo = (uint32_t *)entB;
-        hipLaunchKernelGGL((k_scatter<true, uint32_t>), pgrid, block, 0, s, a, (const uint32_t *)nullptr, c_E, 0, c_hist, l.n_tiles,
-                           ei, (const uint32_t *)nullptr);
+        if (old_pass0)
+            hipLaunchKernelGGL((k_scatter<true, uint32_t>), pgrid, block, 0, s, a, (const uint32_t *)nullptr, c_E, 0, c_hist, l.n_tiles,
+                               ei, (const uint32_t *)nullptr);
+        else
+            hipLaunchKernelGGL((k_xscatter0<uint32_t, XS0_NT_NARROW>), xs0_grid(l.n_tiles, XS0_NT_NARROW), dim3(XS0_NT_NARROW), 0, s, a,
+                               c_hist, l.n_tiles, ei);
         pt.mark("k_scatter<bases>");
+        if (!getenv("KMERS_X_NO_FUSED")) {  // env: A-B runs against k_scatter<entries> + k_rle
+            // the last pass writes the CSR arrays itself (see "fused emit" above)
+            uint32_t *tstart = regs0 + 2 * (RADIX + 1);
+            const uint32_t rows = l.n_tiles + RADIX + 2;
+            hipLaunchKernelGGL(k_ftiles, dim3(1), dim3(RADIX), 0, s, (const uint32_t *)regs0, tstart);
+            hipLaunchKernelGGL(k_heads_hist, dim3(rows < (uint32_t)KK_HIST_BLOCKS ? rows : (uint32_t)KK_HIST_BLOCKS), block, 0, s,
+                               (const uint32_t *)ei, (const uint32_t *)regs0, (const uint32_t *)tstart, hist, rows, scal);
+            pt.mark("k_heads_hist");
+            if (int rc = scan_tilehist(hist, rows, bsum, &scal[7], s)) return rc;
+            pt.mark("k_scan");
+            hipLaunchKernelGGL(k_row_ptr_fused, dim3((uint32_t)((M + 1 + 255) / 256)), dim3(256), 0, s, c_hist, (const uint32_t *)tstart,
+                               (const uint32_t *)&scal[7], M, d_row_ind, scal);
+            const uint32_t et = l.n_tiles + RADIX;
+            hipLaunchKernelGGL(k_emit, dim3(et < (uint32_t)PERSIST_BLOCKS ? et : (uint32_t)PERSIST_BLOCKS), block, 0, s,
+                               (const uint32_t *)ei, (const uint32_t *)regs0, (const uint32_t *)tstart, c_hist, (const uint32_t *)total,
+                               first_col, max_nz, d_data, d_col_ind, scal);
+            pt.mark("k_emit");
+            KK_CHECK(hipGetLastError());
+            uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            KK_CHECK(hipMemcpyAsync(h, scal, sizeof h, hipMemcpyDeviceToHost, s));
+            KK_CHECK(hipStreamSynchronize(s));
+            if (!h[6]) {
+                pt.finish();
+                *nnz_out = h[1];
+                if ((uint64_t)h[1] > max_nz) return -2;
+                return 0;
+            }
+            // a column group longer than the look-back / look-ahead allows (one record with millions of bases): the
+            // general path below redoes everything after pass 0
+            if (getenv("KMERS_VERBOSE")) fprintf(stderr, "libkmers: a record too long for the fused emit: X is finished on the general path\n");
+        }
         if (n_pass > 1) {
             hipLaunchKernelGGL(k_hist_entries<uint32_t>, hgrid, block, 0, s, (const uint32_t *)ei, c_E, 8, hist, l.n_tiles);
             pt.mark("k_hist_entries");
@@ -2871,8 +3508,12 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
                            max_nz, d_data, d_col_ind, d_row_ind, tasks, l.task_cap, final_regions, n_pass > 1 ? 8 : 0);
     } else {
         u64 *ei = entA, *eo = entB;
-        hipLaunchKernelGGL((k_scatter<true, u64>), pgrid, block, 0, s, a, (const u64 *)nullptr, c_E, 0, c_hist, l.n_tiles, ei,
-                           (const uint32_t *)nullptr);
+        if (old_pass0)
+            hipLaunchKernelGGL((k_scatter<true, u64>), pgrid, block, 0, s, a, (const u64 *)nullptr, c_E, 0, c_hist, l.n_tiles, ei,
+                               (const uint32_t *)nullptr);
+        else
+            hipLaunchKernelGGL((k_xscatter0<u64, XS0_NT_WIDE>), xs0_grid(l.n_tiles, XS0_NT_WIDE), dim3(XS0_NT_WIDE), 0, s, a, c_hist,
+                               l.n_tiles, ei);
         pt.mark("k_scatter<bases>");
         for (int p = 1; p < n_pass; ++p) {
             const int shift = 8 * p;
