@@ -1971,7 +1971,11 @@ __global__ void k_row_ptr_fused(const uint32_t *headbase, const uint32_t *tstart
 }
 
 // The last pass: stable partition of a tile by h in LDS, then every wave turns a contiguous eighth of the partitioned
-// tile into CSR entries.
+// tile into CSR entries.  The valid-window totals of the tile's columns (a tile of a region covers ~900 consecutive
+// columns on a transcriptome) are staged in LDS first: one gather instruction over 64 different lines per round kept the
+// CU's address path busy for longer than everything else in the emit (ablation: 0.85 ms of 2.57).
+constexpr uint32_t EM_TOT_CAP = 2048;  // columns whose totals are staged (a sparser tile gathers the rest from memory)
+
 __global__ __launch_bounds__(NT, 4) void k_emit(const uint32_t *ent, const uint32_t *regions, const uint32_t *tstart,
                                                 const uint32_t *headbase, const uint32_t *rec_total, uint64_t first_col,
                                                 uint64_t max_nz, float *data, uint64_t *col_ind, uint32_t *scal) {
@@ -1979,10 +1983,11 @@ __global__ __launch_bounds__(NT, 4) void k_emit(const uint32_t *ent, const uint3
     __shared__ uint32_t wcnt[NW][RADIX];
     __shared__ uint32_t s_reg[RADIX + 1], s_ts[RADIX + 1];
     __shared__ uint32_t sseen[RADIX], sextra[RADIX], shb[RADIX];
-    __shared__ uint32_t sadj_all[NW][RADIX];  // per wave: see the emit loop
+    __shared__ uint32_t stot[EM_TOT_CAP];
     __shared__ uint32_t stmp[NW], s_c[2];
     static_assert(NW * RADIX * 8 <= FT * 4, "match masks alias the entry staging");
-    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
+    const uint32_t tid = threadIdx.x, lane = lane_id();
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // (scalar: the emit sweep branches on it)
     for (uint32_t i = tid; i <= RADIX; i += NT) {
         s_reg[i] = regions[i];
         s_ts[i] = tstart[i];
@@ -1993,23 +1998,33 @@ __global__ __launch_bounds__(NT, 4) void k_emit(const uint32_t *ent, const uint3
     const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < n_ft) ? t0 + per : n_ft;
     if (t0 >= t1) return;
     u64 *const smask = reinterpret_cast<u64 *>(stage);
-    uint32_t *const sadj = sadj_all[w];
-    uint32_t e[IPT], probe = NONE;
+    uint32_t e[IPT], probe = NONE, e_first = 0, e_last = 0;
     FTile ft{0, 0, 0, 0, 0};
     auto load_tile = [&](uint32_t t) {
         ft = ftile_of(s_ts, s_reg, t);
-        const uint32_t s0 = ft.begin + w * WCHUNK;
+        // (the tile's bounds are the same for every thread: scalar, so that the loads take a scalar base + 32-bit offset)
+        ft.begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)ft.begin);
+        ft.end = (uint32_t)__builtin_amdgcn_readfirstlane((int)ft.end);
+        ft.rbegin = (uint32_t)__builtin_amdgcn_readfirstlane((int)ft.rbegin);
+        ft.rend = (uint32_t)__builtin_amdgcn_readfirstlane((int)ft.rend);
+        const uint32_t *const tp = ent + ft.begin;
+        const uint32_t nn = ft.end - ft.begin;
+        uint32_t o0 = w * WCHUNK + lane;
+        asm volatile("" : "+v"(o0));  // (opaque: otherwise the 16 offsets are kept in registers across the tile loop)
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
-            const uint32_t i = s0 + j * 64 + lane;
-            e[j] = (i < ft.end) ? ent[i] : 0u;
+            const uint32_t o = o0 + j * 64;
+            e[j] = (o < nn) ? tp[o] : 0u;
         }
+        e_first = tp[0];
+        e_last = tp[nn - 1];
         probe = NONE;
         if (w == 0 && ft.begin >= ft.rbegin + 1u + lane) probe = ent[ft.begin - 1u - lane];       // look back
         if (w == NW - 1 && ft.end + lane < ft.rend) probe = ent[ft.end + lane];                    // look ahead
     };
     load_tile(t0);
     uint32_t gb = (tid < RADIX) ? headbase[(uint64_t)t0 * RADIX + tid] : 0u;
+    KK_STAMP_BEGIN();
     for (uint32_t tile = t0; tile < t1; ++tile) {
         const FTile f = ft;
         const uint32_t n = f.end - f.begin;  // entries of the tile (>= 1)
@@ -2023,12 +2038,22 @@ __global__ __launch_bounds__(NT, 4) void k_emit(const uint32_t *ent, const uint3
             shb[tid] = gb;
             if (tile + 1 < t1) gb = headbase[(uint64_t)(tile + 1) * RADIX + tid];
         }
+        // the totals of the tile's columns [cf, cl], on their way while the tile is ranked
+        const uint32_t cf = fe_col(e_first), cl = fe_col(e_last);
+        constexpr int TQ = EM_TOT_CAP / NT;
+        uint32_t totq[TQ];
+#pragma unroll
+        for (int q = 0; q < TQ; ++q) {
+            const uint32_t c = cf + tid + (uint32_t)q * NT;
+            totq[q] = (c <= cl) ? rec_total[c] : 0u;
+        }
         lds_sync();
+        KK_STAMP(0);
         // ---- the neighbours of the tile inside its region (waves 0 and NW - 1, while the others rank)
         if (w == 0) {
             uint32_t c0 = NONE;
             if (f.begin > f.rbegin) {
-                c0 = fe_col((uint32_t)__builtin_amdgcn_readfirstlane((int)e[0]));
+                c0 = cf;
                 uint32_t at = f.begin, it = 0;
                 bool any = false;
                 for (;;) {
@@ -2051,8 +2076,8 @@ __global__ __launch_bounds__(NT, 4) void k_emit(const uint32_t *ent, const uint3
         }
         if (w == NW - 1) {
             uint32_t c1 = NONE;
-            if (f.end < f.rend) {  // (then the tile is full: its last entry is this wave's last)
-                c1 = fe_col((uint32_t)__builtin_amdgcn_readlane((int)e[IPT - 1], 63));
+            if (f.end < f.rend) {
+                c1 = cl;
                 uint32_t at = f.end, it = 0;
                 bool any = false;
                 for (;;) {
@@ -2078,7 +2103,7 @@ __global__ __launch_bounds__(NT, 4) void k_emit(const uint32_t *ent, const uint3
         asm volatile("" : "+v"(wl));
         uint32_t *const wrow = &wcnt[w][0];
         u64 *const wmask = &smask[w * RADIX];
-        uint32_t rank[IPT];
+        uint32_t rank2[IPT / 2];  // two 16-bit ranks per register (0xFFFF: no entry); a rank is < FT = 8192
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             const bool ok = wl + j * 64 < n;
@@ -2092,7 +2117,8 @@ __global__ __launch_bounds__(NT, 4) void k_emit(const uint32_t *ent, const uint3
             }
             const uint32_t m_lo = (uint32_t)m, m_hi = (uint32_t)(m >> 32);
             const uint32_t below = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
-            rank[j] = ok ? (before + below) : NONE;
+            const uint32_t rk = ok ? (before + below) : 0xFFFFu;
+            rank2[j >> 1] = (j & 1) ? (rank2[j >> 1] | (rk << 16)) : rk;
             if (ok && below == 0) {
                 wrow[d] = before + (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi);
                 wmask[d] = 0ull;
@@ -2100,7 +2126,9 @@ __global__ __launch_bounds__(NT, 4) void k_emit(const uint32_t *ent, const uint3
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
+        KK_STAMP(1);
         lds_sync();
+        KK_STAMP(2);
         uint32_t dtot = 0;
         uint32_t wc[NW];
         if (tid < RADIX) {
@@ -2116,109 +2144,169 @@ __global__ __launch_bounds__(NT, 4) void k_emit(const uint32_t *ent, const uint3
 #pragma unroll
             for (int i = 0; i < NW; ++i) wcnt[i][tid] = dstart + wc[i];
         }
+#pragma unroll
+        for (int q = 0; q < TQ; ++q) stot[tid + (uint32_t)q * NT] = totq[q];
         lds_sync();
+        KK_STAMP(3);
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
-            if (rank[j] != NONE) stage[wrow[e[j] >> 24] + rank[j]] = e[j];
+            const uint32_t rk = (j & 1) ? (rank2[j >> 1] >> 16) : (rank2[j >> 1] & 0xFFFFu);
+            if (rk != 0xFFFFu) stage[wrow[e[j] >> 24] + rk] = e[j];
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         if (tile + 1 < t1) load_tile(tile + 1);
+        KK_STAMP(4);
         lds_sync();
+        KK_STAMP(5);
+        // Everything that was loaded for the NEXT tile is waited for HERE, before this tile's stores are issued: vmcnt
+        // counts loads and stores in one queue and the compiler cannot count the stores of the emit loop, so a wait that
+        // came after them would be vmcnt(0) and drain every store before the next tile could be ranked -- with all
+        // workgroups in step, the chip then alternates between an LDS-bound and a store-bound phase.  (The empty asm uses
+        // the registers, which makes the compiler wait for their loads now; afterwards it has nothing pending on them.)
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) asm volatile("" : "+v"(e[j]));
+        asm volatile("" : "+v"(e_first), "+v"(e_last), "+v"(probe), "+v"(gb));
         const uint32_t c0 = s_c[0], c1 = s_c[1];
         // ---- emit: wave w owns stage[a, b); v[k] = stage[a + 64 k + lane]
         const uint32_t a = w * WCHUNK;
+#ifdef EM_NOEMIT
+        if (a > n) {
+#else
         if (a < n) {
+#endif
             const uint32_t b = (a + WCHUNK < n) ? a + WCHUNK : n;
-            uint32_t v[IPT];
-            u64 fm[IPT], hm[IPT];  // group firsts / heads (wave-uniform masks)
-#pragma unroll
-            for (int k = 0; k < IPT; ++k) {
-                const uint32_t i = a + k * 64 + lane;
-                const bool in = i < b;
-                uint32_t x = 0, p = 0;
-                if (in) {
-                    x = stage[i];
-                    p = (i > 0) ? stage[i - 1] : ~x;
-                }
-                v[k] = x;
-                const bool first = in && x != p;
-                bool head = first;
-                if (first && fe_col(x) == c0) head = sseen[x >> 24] == 0u;  // (rare: the tile's first column)
-                fm[k] = __ballot(first);
-                hm[k] = __ballot(head);
-            }
-            // first group-first at or after b (the last group of the chunk ends there); n if none
-            uint32_t after = n;
+            // lanes of a round that are heads although they start a group: the group began in front of the tile
+            auto not_heads = [&](uint32_t x, u64 firsts) -> u64 {
+                if (c0 == NONE) return 0ull;                                    // (workgroup-uniform)
+                const u64 cand = firsts & __ballot(fe_col(x) == c0);
+                if (cand == 0ull) return 0ull;                                  // (wave-uniform) nearly always
+                bool seen = false;
+                if ((cand >> lane) & 1ull) seen = sseen[x >> 24] != 0u;
+                return __ballot(seen);
+            };
+            // One sweep over the chunk, a round (64 entries) at a time, with the NEXT round already read: the last group of a
+            // round ends where the next round's first group starts (or further on: the rare loop below).
+            auto firsts_of = [&](uint32_t base, uint32_t x, uint32_t pv) -> u64 {  // lanes of [base, base + 64) that start a group
+                if (base >= b) return 0ull;
+                const uint32_t left = b - base;
+                const u64 inm = left >= 64u ? ~0ull : ((1ull << left) - 1ull);
+                return __ballot(x != pv || base + lane == 0u) & inm;
+            };
+            uint32_t x = stage[(a + lane) & (FT - 1)];  // (past b: whatever is there, masked)
+            uint32_t pv = lane_prev(x);
             {
-                const uint32_t last = stage[b - 1];
-                for (uint32_t q = b; q < n; q += 64) {
-                    const uint32_t i = q + lane;
-                    const u64 dm = __ballot(i < n && stage[i] != last);
-                    if (dm) {
-                        after = q + (uint32_t)__ffsll((long long)dm) - 1u;
-                        break;
-                    }
-                }
+                const uint32_t c = stage[a ? a - 1u : 0u];
+                if (lane == 0) pv = c;
             }
+            u64 fmc = firsts_of(a, x, pv);
             // heads of the chunk's first digit that lie in front of the chunk (its run may start in an earlier wave's part)
-            const uint32_t h_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[0]) >> 24;
+            const uint32_t h_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)x) >> 24;
             uint32_t run = 0;  // heads of digit h_first in stage[dstart(h_first), a)
             {
                 const uint32_t ds = wcnt[0][h_first];
                 for (uint32_t q = ds; q < a; q += 64) {
                     const uint32_t i = q + lane;
-                    bool head = false;
-                    if (i < a) {
-                        const uint32_t x = stage[i], p = (i > 0) ? stage[i - 1] : ~x;
-                        head = x != p;
-                        if (head && fe_col(x) == c0) head = sseen[x >> 24] == 0u;
+                    const uint32_t y = stage[i & (FT - 1)], py = stage[(i ? i - 1u : 0u) & (FT - 1)];
+                    const u64 firsts = __ballot(i < a && (y != py || i == 0u));
+                    run += (uint32_t)__popcll(firsts & ~not_heads(y, firsts));
+                }
+            }
+            // Two copies of the sweep: with every column total of the tile staged in LDS (the rule) the loop contains NO
+            // global load, so nothing in it waits on the memory queue and the stores drain behind the next tile's ranking
+            // (a load's wait is vmcnt(0) here: it would hold every round until the previous round's stores have landed).
+            // Output position of a head = shb[h] + heads of digit h in front of it in the tile: inside the round from the
+            // lane where the digit's run starts (a mask of the digit changes), else the count carried from round to round.
+            auto sweep = [&](auto staged) {
+                uint32_t dig_run = run;  // heads of the digit that is open at the start of the round, in front of the round
+#pragma unroll 2
+                for (uint32_t base = a; base < b; base += 64) {
+                    const uint32_t nb = base + 64;
+                    const uint32_t xn = stage[(nb + lane) & (FT - 1)];
+                    uint32_t pn = lane_prev(xn);
+                    const uint32_t xl = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+                    if (lane == 0) pn = xl;
+                    const u64 fmn = firsts_of(nb, xn, pn);
+                    const uint32_t h = x >> 24, c = fe_col(x);
+                    const u64 dchg = fmc & __ballot(h != (pv >> 24));  // lanes where another digit's run starts
+                    const u64 hmk = fmc & ~not_heads(x, fmc);
+                    if (fmc != 0ull) {  // (wave-uniform; a round inside one long group has nothing to emit)
+                        const uint32_t hb = shb[h];
+                        uint32_t total = 1u;
+#ifndef EM_NOGATHER
+                        if constexpr (decltype(staged)::value)
+                            total = stot[(c - cf) & (EM_TOT_CAP - 1)];
+                        else
+                            total = rec_total[c];
+#endif
+                        // where the round's last group ends
+                        uint32_t nxt_last;
+                        if (fmn != 0ull) {
+                            nxt_last = nb + (uint32_t)__ffsll((long long)fmn) - 1u;
+                        } else {  // the chunk ends here, or a group longer than a round: look for the next different entry
+                            const uint32_t lastv = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)(63u - (uint32_t)__clzll((long long)fmc)));
+                            nxt_last = n;
+                            for (uint32_t q = nb; q < n; q += 64) {
+                                const uint32_t i = q + lane;
+                                const u64 dm = __ballot(i < n && stage[i & (FT - 1)] != lastv);
+                                if (dm) {
+                                    nxt_last = q + (uint32_t)__ffsll((long long)dm) - 1u;
+                                    break;
+                                }
+                            }
+                        }
+                        const uint32_t i = base + lane;
+                        const u64 le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+                        const u64 chg_le = dchg & le;
+                        const uint32_t s0 = chg_le ? 63u - (uint32_t)__clzll((long long)chg_le) : 0u;  // my digit's first lane here
+                        const u64 hseg = hmk & ~lanes_below(s0);
+                        const uint32_t hbefore = __builtin_amdgcn_mbcnt_hi((uint32_t)(hseg >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hseg, 0u)) +
+                                                 (chg_le ? 0u : dig_run);
+                        if ((hmk >> lane) & 1ull) {
+                            const u64 above = (lane == 63) ? 0ull : (fmc >> (lane + 1));
+                            const uint32_t nxt = above ? i + (uint32_t)__ffsll((long long)above) : nxt_last;
+                            uint32_t cnt = nxt - i;
+                            if (c == c1) cnt += sextra[h];  // (rare) the group goes on behind the tile
+#ifdef EM_LINEAR  // diagnostic builds (wrong results): every wave stores to a stream of its own, in whole lines
+                            const uint64_t o = ((uint64_t)tile * NW + w) * WCHUNK + (base - a) + lane + (hb & 0u);
+#else
+                            const uint64_t o = (uint32_t)(hb + hbefore);
+#endif
+                            if (o < max_nz) {
+                                // reference: float(count) / total_count with total_count uint32_t: both operands are rounded
+                                // to float, then one IEEE float division (hipcc's default float division is correctly rounded)
+#ifdef EM_NOSTORE
+                                if (total == 0x7FFFFFFFu)
+#endif
+                                data[o] = (float)cnt / (float)total;
+#ifdef EM_NOSTORE
+                                if (total == 0x7FFFFFFFu)
+#endif
+                                col_ind[o] = first_col + c;
+                            }
+                        }
+                        // the digit that is open behind this round, and its heads so far
+                        if (dchg) {
+                            const uint32_t sl = 63u - (uint32_t)__clzll((long long)dchg);
+                            dig_run = (uint32_t)__popcll(hmk & ~lanes_below(sl));
+                        } else {
+                            dig_run += (uint32_t)__popcll(hmk);
+                        }
                     }
-                    run += (uint32_t)__popcll(__ballot(head));
+                    x = xn;
+                    pv = pn;
+                    fmc = fmn;
                 }
-            }
-            // sadj[h] (this wave's own table) = output position of digit h's first head minus the number of heads of THIS
-            // CHUNK in front of the digit's run, so that a head's position is sadj[h] + (heads of the chunk in front of it).
-            // Set by the lane that holds the first entry of the run; for a run that began in front of the chunk, here.
-            if (lane == 0) sadj[h_first] = shb[h_first] + run;
-            uint32_t nxt_after[IPT];
-            {
-                uint32_t nh = after;
-#pragma unroll
-                for (int k = IPT - 1; k >= 0; --k) {
-                    nxt_after[k] = nh;
-                    if (fm[k]) nh = a + k * 64 + (uint32_t)__ffsll((long long)fm[k]) - 1u;
-                }
-            }
-            uint32_t cnt_heads = 0;  // heads of the chunk in front of round k
-#pragma unroll
-            for (int k = 0; k < IPT; ++k) {
-                if (fm[k] == 0ull) continue;  // (wave-uniform) a round inside one long group
-                const uint32_t i = a + k * 64 + lane;
-                const uint32_t x = v[k], h = x >> 24;
-                const bool is_first = (fm[k] >> lane) & 1ull, is_head = (hm[k] >> lane) & 1ull;
-                const uint32_t hr = cnt_heads + (uint32_t)__popcll(hm[k] & lanes_below(lane));  // heads of the chunk in front of me
-                // a digit's run starts at i (the chunk's first entry was dealt with above)
-                if (is_first && i > a && (stage[i - 1] >> 24) != h) sadj[h] = shb[h] - hr;
-                if (is_head) {
-                    const u64 above = (lane == 63) ? 0ull : (fm[k] >> (lane + 1));
-                    const uint32_t nxt = above ? i + (uint32_t)__ffsll((long long)above) : nxt_after[k];
-                    uint32_t cnt = nxt - i;
-                    const uint32_t c = fe_col(x);
-                    if (c == c1) cnt += sextra[h];  // (rare) the group goes on behind the tile
-                    const uint64_t o = (uint64_t)sadj[h] + hr;
-                    if (o < max_nz) {
-                        // reference: float(count) / total_count with total_count uint32_t: both operands are rounded to
-                        // float, then one IEEE float division (hipcc's default float division is correctly rounded)
-                        const uint32_t total = rec_total[c];
-                        data[o] = (float)cnt / (float)total;
-                        col_ind[o] = first_col + c;
-                    }
-                }
-                cnt_heads += (uint32_t)__popcll(hm[k]);
-            }
+            };
+            if (cl - cf < EM_TOT_CAP)  // (workgroup-uniform)
+                sweep(std::true_type{});
+            else
+                sweep(std::false_type{});
         }
+        KK_STAMP(6);
         lds_sync();
+        KK_STAMP(7);
     }
+    KK_STAMP_END(8);
 }
 
 // ------------------------------------------------------------------------------------------------------

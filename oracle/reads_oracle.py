@@ -3,9 +3,11 @@
 Restatement of the reference's read simulator, kmerexpr/simulate_reads.py:54-122, and of the FASTA reader it uses,
 kmerexpr/fasta.py:19-46: the same numpy calls in the same order (np.random.seed(42); dirichlet; choice(T, N, p);
 then one choice(len - L + 1) per read), the same reads file.  The saving of parameters (:109-110) is replaced by
-returning them.  PINNED by construction rather than by fixtures: the reference holds no output of this function, and
-importing it fails here (kmerexpr.utils needs numba / MKL); every line that draws a random number is the reference's
-own call on numpy's frozen legacy generator."""
+returning them.  The FASTA reader half is PINNED to the reference's own file: tests/golden/fasta_py.json holds what
+/root/reference/kmerexpr/fasta.py yields on 40 committed inputs (oracle/make_golden_py.py imports it by path in the build
+container; tests/test_fasta_py_golden.py).  The sampling half is pinned by construction only: the reference holds no
+output of simulate_reads, and importing it fails here (kmerexpr.utils needs numba / MKL); every line that draws a random
+number is the reference's own call on numpy's frozen legacy generator."""
 import numpy as np
 
 

@@ -34,26 +34,7 @@ def test_sampler_equals_reference_calls(iso, tmp_path, N, L, alpha):
         assert (want["lengths"] == 1).any()                 # the 80-base record: choice(1) draws nothing
 
 
-def awkward_fasta(path, seed=0):
-    """A FASTA on which the reference's two readers differ (src/libkmers.cpp:302-318 vs kmerexpr/fasta.py:19-46): text
-    before the first header, CRLF and lone-CR line ends, blank and whitespace-only lines, leading / trailing / inner
-    blanks of every kind python strips, an empty later header, a NUL inside a sequence."""
-    rng = np.random.default_rng(seed)
-    rnd = lambda n: bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n))
-    b = bytearray()
-    b += b"some text before the first header\nACGTACGTACGT\n\n"
-    b += b">r1 crlf lines\r\n" + rnd(70) + b"\r\n" + rnd(70) + b"\r\n  " + rnd(33) + b" \t\r\n\r\n"
-    b += b">r2 PREDICTED: dropped\n" + rnd(300) + b"\n"
-    b += b">r3 lone cr\r" + rnd(120) + b"\r" + rnd(55) + b"\r"
-    b += b">r4 header ends with a lone cr\r" + rnd(90) + b"\n\n   \n\t\n" + rnd(90) + b"\n"
-    b += b">r5 inner blanks\n\t" + rnd(40) + b" " + rnd(40) + b"\x0b" + rnd(30) + b"\x0c\n \x1c\x1d" + rnd(64) + b"\x1f\n"
-    b += b">\n" + rnd(200) + b"\n"                                     # an empty header that is not the first one
-    b += b">r7 nul inside\n" + rnd(50) + b"\x00" + rnd(150) + b"\n"
-    b += b">r8 short\nACGT\n"
-    b += b">r9 N and lower case\n" + rnd(60) + b"NNNnnacgt" + rnd(120) + b"   \n" + rnd(30)     # no newline at the end
-    with open(path, "wb") as f:
-        f.write(bytes(b))
-    return path
+awkward_fasta = kmtest.awkward_fasta
 
 
 def _norm(text):
@@ -82,13 +63,7 @@ def test_isoform_list_fuzz(tmp_path, seed):
     """Random files from an alphabet of bases, '>' , every line end and every blank python strips: the store under the
     fasta.py rules == the restated fasta.py reader, whole and in byte-range shards."""
     from kmers_amd.store import MODE_FASTA_PY, Store
-    rng = np.random.default_rng(900 + seed)
-    alphabet = [b"A", b"C", b"G", b"T", b"N", b"a", b">", b"\n", b"\r", b"\r\n", b" ", b"\t", b"\x0b", b"\x0c", b"\x1c", b"\x1f",
-                b"\x00", b"PREDICTED", b">h", b"\n>rec ", b"ACGTACGTAC"]
-    weights = np.array([8, 8, 8, 8, 1, 1, 0.3, 2, 0.7, 0.7, 1, 0.5, 0.2, 0.2, 0.2, 0.2, 0.2, 0.2, 0.5, 1.5, 6], float)
-    text = b"".join(alphabet[i] for i in rng.choice(len(alphabet), int(rng.integers(0, 3000)), p=weights / weights.sum()))
-    if rng.random() < 0.5:
-        text = b">first\n" + text
+    text = kmtest.fuzz_fasta_bytes(seed)
     p = tmp_path / "f.fsa"
     p.write_bytes(text)
     for L in (0, 7, 40):

@@ -34,7 +34,7 @@ for _ in range(n):
 print("ablate =", os.environ.get("KK_ABLATE", "0"), {r[0]: round(r[1] / n, 3) for r in _lib.profile_table()})
 assert lib.kmers_hip_debug_stamps(out, 1) == 0
 names = ["zero+commit", "ranking", "barrier", "digit scan", "lds scatter+prefetch", "barrier", "write-out", "end barrier"]
-for which, off in (("k_scatter<bases>", 0), ("k_scatter<entries>", 8)):
+for which, off in (("k_scatter<bases> (old pass 0)", 0), ("k_scatter<entries> / k_emit (fused)", 8)):
     tot = sum(out[off:off + 8]) or 1
     print(which, "total cycles (sum over workgroups, per build):", tot // n)
     for i, nm in enumerate(names):
