@@ -155,6 +155,14 @@ void kmers_hip_profile_enable(int on);
 int kmers_hip_profile_count(void);
 int kmers_hip_profile_get(int i, char *name, size_t name_cap, double *ms_total, uint64_t *calls);
 
+/* Path switches for tests and same-run A/B measurements (process-wide; never needed in production).  The library reads
+ * the environment variables of the same meaning ONCE, at its first use in the process (KMERS_Y_ATOMICS, KMERS_Y_CAP,
+ * KMERS_FORCE_WIDE, KMERS_X_PATH=tables|rle, KMERS_X_OLD_PASS0, KMERS_X_CHUNK_POS, KMERS_VERBOSE); afterwards only this call
+ * changes them: name = "y_atomics", "y_cap", "force_wide", "x_path" (0 default, 1 tables, 2 rle), "old_pass0",
+ * "x_chunk_pos", "verbose", or "reset" (re-read the environment).  Returns 0, or KMERS_ERR_BAD_ARG for an unknown name.
+ * No counterpart in the reference. */
+int kmers_hip_debug_knob(const char *name, long long value);
+
 /* Diagnostic builds only (`python -m kmers_amd.build --stamps`, -DKK_STAMPS): cycle sums of the phases of the two
  * partition kernels (s_memtime, wave 0 of every workgroup).  The product build returns KMERS_ERR_BAD_ARG. */
 int kmers_hip_debug_stamps(unsigned long long *out16, int reset);

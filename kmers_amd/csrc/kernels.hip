@@ -1974,9 +1974,12 @@ __global__ void k_row_ptr_fused(const uint32_t *headbase, const uint32_t *tstart
 // tile into CSR entries.  The valid-window totals of the tile's columns (a tile of a region covers ~900 consecutive
 // columns on a transcriptome) are staged in LDS first: one gather instruction over 64 different lines per round kept the
 // CU's address path busy for longer than everything else in the emit (ablation: 0.85 ms of 2.57).
+#ifndef EM_WAVES
+#define EM_WAVES 4   // waves per SIMD the register allocation aims at (6: three workgroups per CU)
+#endif
 constexpr uint32_t EM_TOT_CAP = 2048;  // columns whose totals are staged (a sparser tile gathers the rest from memory)
 
-__global__ __launch_bounds__(NT, 4) void k_emit(const uint32_t *ent, const uint32_t *regions, const uint32_t *tstart,
+__global__ __launch_bounds__(NT, EM_WAVES) void k_emit(const uint32_t *ent, const uint32_t *regions, const uint32_t *tstart,
                                                 const uint32_t *headbase, const uint32_t *rec_total, uint64_t first_col,
                                                 uint64_t max_nz, float *data, uint64_t *col_ind, uint32_t *scal) {
     __shared__ __attribute__((aligned(16))) uint32_t stage[FT];  // the partitioned tile; first the match masks
@@ -2218,7 +2221,7 @@ __global__ __launch_bounds__(NT, 4) void k_emit(const uint32_t *ent, const uint3
             // lane where the digit's run starts (a mask of the digit changes), else the count carried from round to round.
             auto sweep = [&](auto staged) {
                 uint32_t dig_run = run;  // heads of the digit that is open at the start of the round, in front of the round
-#pragma unroll 2
+#pragma unroll 1
                 for (uint32_t base = a; base < b; base += 64) {
                     const uint32_t nb = base + 64;
                     const uint32_t xn = stage[(nb + lane) & (FT - 1)];
@@ -2233,10 +2236,7 @@ __global__ __launch_bounds__(NT, 4) void k_emit(const uint32_t *ent, const uint3
                         const uint32_t hb = shb[h];
                         uint32_t total = 1u;
 #ifndef EM_NOGATHER
-                        if constexpr (decltype(staged)::value)
-                            total = stot[(c - cf) & (EM_TOT_CAP - 1)];
-                        else
-                            total = rec_total[c];
+                        if constexpr (decltype(staged)::value) total = stot[(c - cf) & (EM_TOT_CAP - 1)];  // (any lane: LDS)
 #endif
                         // where the round's last group ends
                         uint32_t nxt_last;
@@ -2266,6 +2266,9 @@ __global__ __launch_bounds__(NT, 4) void k_emit(const uint32_t *ent, const uint3
                             const uint32_t nxt = above ? i + (uint32_t)__ffsll((long long)above) : nxt_last;
                             uint32_t cnt = nxt - i;
                             if (c == c1) cnt += sextra[h];  // (rare) the group goes on behind the tile
+#ifndef EM_NOGATHER
+                            if constexpr (!decltype(staged)::value) total = rec_total[c];  // (a head's column: in range)
+#endif
 #ifdef EM_LINEAR  // diagnostic builds (wrong results): every wave stores to a stream of its own, in whole lines
                             const uint64_t o = ((uint64_t)tile * NW + w) * WCHUNK + (base - a) + lane + (hb & 0u);
 #else
@@ -3016,6 +3019,47 @@ __global__ void k_fix_escapes(const DDEscape *esc, const uint32_t *scal, uint32_
 // host launchers
 // ------------------------------------------------------------------------------------------------------
 
+static std::mutex g_knob_mu;
+static Knobs g_knobs;
+static bool g_knobs_read = false;
+static void read_knobs_locked() {
+    Knobs k;
+    auto num = [](const char *name) -> unsigned long long {
+        const char *e = getenv(name);
+        return e ? strtoull(e, nullptr, 10) : 0ull;
+    };
+    k.y_atomics = getenv("KMERS_Y_ATOMICS") != nullptr;
+    if (getenv("KMERS_Y_CAP")) k.y_cap = num("KMERS_Y_CAP") ? num("KMERS_Y_CAP") : 1;
+    k.force_wide = getenv("KMERS_FORCE_WIDE") != nullptr;
+    if (const char *e = getenv("KMERS_X_PATH")) k.x_path = !strcmp(e, "tables") ? 1 : (!strcmp(e, "rle") ? 2 : 0);
+    k.old_pass0 = getenv("KMERS_X_OLD_PASS0") != nullptr;
+    k.x_chunk_pos = num("KMERS_X_CHUNK_POS");
+    k.verbose = (int)num("KMERS_VERBOSE");
+    g_knobs = k;
+    g_knobs_read = true;
+}
+const Knobs &knobs() {
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    if (!g_knobs_read) read_knobs_locked();
+    return g_knobs;
+}
+int set_knob(const char *name, long long value) {
+    if (!name) return -12;
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    if (!g_knobs_read) read_knobs_locked();
+    const std::string n(name);
+    if (n == "reset") read_knobs_locked();
+    else if (n == "y_atomics") g_knobs.y_atomics = value != 0;
+    else if (n == "y_cap") g_knobs.y_cap = value > 0 ? (unsigned long long)value : 0;
+    else if (n == "force_wide") g_knobs.force_wide = value != 0;
+    else if (n == "x_path") g_knobs.x_path = (int)value;
+    else if (n == "old_pass0") g_knobs.old_pass0 = value != 0;
+    else if (n == "x_chunk_pos") g_knobs.x_chunk_pos = value > 0 ? (unsigned long long)value : 0;
+    else if (n == "verbose") g_knobs.verbose = (int)value;
+    else return -12;
+    return 0;
+}
+
 // Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline object).
 static bool g_prof_on = false;
 static std::mutex g_prof_mu;
@@ -3290,7 +3334,8 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         }
         return 0;
     }
-    if (getenv("KMERS_Y_ATOMICS")) {  // env: A-B runs against the plain global-atomics kernel
+    const Knobs kn = knobs();
+    if (kn.y_atomics) {  // knob: A-B runs against the plain global-atomics kernel
         const uint32_t grid = (uint32_t)(n_tiles < 2048 ? n_tiles : 2048);
         hipLaunchKernelGGL(k_count_y_global, dim3(grid), dim3(NT), 0, s, a, d_counts, n_tiles);
         pt.mark("k_count_y_global");
@@ -3340,7 +3385,7 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         uint64_t cap64 = (uint64_t)nt * TILE / n_ranges;
         cap64 += cap64 / 4;  // 1.25 x the mean range (of positions: >= entries)
         if (cap64 < 2 * (uint64_t)YS_OVF_CHUNK) cap64 = 2 * (uint64_t)YS_OVF_CHUNK;
-        if (const char *e = getenv("KMERS_Y_CAP")) cap64 = strtoull(e, nullptr, 10) ? strtoull(e, nullptr, 10) : 1;  // env: tests
+        if (kn.y_cap) cap64 = kn.y_cap;  // knob: tests
         const uint32_t cap = (uint32_t)(cap64 > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap64);
         const dim3 grid(nt);
         const dim3 pgrid(nt < (uint32_t)PERSIST_BLOCKS ? nt : (uint32_t)PERSIST_BLOCKS);
@@ -3499,16 +3544,16 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
 
     // 5 <= K <= 8: the per-isoform LDS tables are selected with KMERS_X_PATH=tables.  Measured on config 2 they are not
     // yet the faster of the two paths (6.0 ms against 5.6 ms: DESIGN.md section 4), so the partition path stays the default.
+    const Knobs kn = knobs();
     {
-        const char *e = getenv("KMERS_X_PATH");
-        const bool want_tables = e && !strcmp(e, "tables") && !getenv("KMERS_FORCE_WIDE");
+        const bool want_tables = kn.x_path == 1 && !kn.force_wide;
         const bool fits = K >= 5 && K <= 8 && n_rec <= DD_MAX_REC;
         if (fits && want_tables) {
             const int rc = build_x_tables(l, d_bases, bases_words, d_valid, valid_words, d_rec_start, n_pos, n_rec, first_col, K,
                                           d_data, d_col_ind, d_row_ind, max_nz, ws, nnz_out, s, pt);
             if (rc != 1) return rc;
             pt.on = false;  // (its timeline was closed by the attempt above)
-            if (getenv("KMERS_VERBOSE")) fprintf(stderr, "libkmers: a k-mer count left the table's range: X is rebuilt on the general path\n");
+            if (kn.verbose) fprintf(stderr, "libkmers: a k-mer count left the table's range: X is rebuilt on the general path\n");
             KK_CHECK(hipMemsetAsync(scal, 0, 64, s));
             KK_CHECK(hipMemsetAsync(total, 0, n_rec * 4, s));
         }
@@ -3527,10 +3572,10 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     const dim3 pgrid(l.n_tiles < (uint32_t)PERSIST_BLOCKS ? l.n_tiles : (uint32_t)PERSIST_BLOCKS);
     const dim3 hgrid(l.n_tiles < (uint32_t)KK_HIST_BLOCKS ? l.n_tiles : (uint32_t)KK_HIST_BLOCKS);
     const int n_pass = (2 * K + 7) / 8;
-    const bool old_pass0 = getenv("KMERS_X_OLD_PASS0") != nullptr;  // env: A-B runs against the position-ordered pass 0
+    const bool old_pass0 = kn.old_pass0;  // knob: A-B runs against the position-ordered pass 0
 
     // K <= 8 and at most 2^24 records: 4-byte entries (digit byte << 24 | column), else 8-byte (k-mer id << 32 | column)
-    const bool narrow = (K <= 8) && (n_rec <= (1ull << 24)) && !getenv("KMERS_FORCE_WIDE");  // env: tests / A-B runs
+    const bool narrow = (K <= 8) && (n_rec <= (1ull << 24)) && !kn.force_wide;  // knob: tests / A-B runs
     uint32_t *regs0 = (uint32_t *)(ws + l.off_regions), *regs1 = regs0 + (RADIX + 1);
     const uint32_t *c_hist = hist, *c_E = &scal[0];
 
@@ -3549,7 +3594,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
             hipLaunchKernelGGL((k_xscatter0<uint32_t, XS0_NT_NARROW>), xs0_grid(l.n_tiles, XS0_NT_NARROW), dim3(XS0_NT_NARROW), 0, s, a,
                                c_hist, l.n_tiles, ei);
         pt.mark("k_scatter<bases>");
-        if (!getenv("KMERS_X_NO_FUSED")) {  // env: A-B runs against k_scatter<entries> + k_rle
+        if (kn.x_path != 2) {  // knob: A-B runs against k_scatter<entries> + k_rle
             // the last pass writes the CSR arrays itself (see "fused emit" above)
             uint32_t *tstart = regs0 + 2 * (RADIX + 1);
             const uint32_t rows = l.n_tiles + RADIX + 2;
@@ -3578,7 +3623,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
             }
             // a column group longer than the look-back / look-ahead allows (one record with millions of bases): the
             // general path below redoes everything after pass 0
-            if (getenv("KMERS_VERBOSE")) fprintf(stderr, "libkmers: a record too long for the fused emit: X is finished on the general path\n");
+            if (kn.verbose) fprintf(stderr, "libkmers: a record too long for the fused emit: X is finished on the general path\n");
         }
         if (n_pass > 1) {
             hipLaunchKernelGGL(k_hist_entries<uint32_t>, hgrid, block, 0, s, (const uint32_t *)ei, c_E, 8, hist, l.n_tiles);

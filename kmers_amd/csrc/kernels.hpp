@@ -21,6 +21,21 @@ bool profile_on();
 void profile_add(const char *name, double ms);  // one launch of `name` took ms (model.hip's own event pairs)
 int read_stamps(unsigned long long *out16, bool reset);  // diagnostic builds (-DKK_STAMPS) only
 
+// Path switches for tests and same-run A/B measurements.  The environment is read ONCE, at the first use in the process
+// (a product call never calls getenv again, so a change of the environment cannot silently switch the kernels of a
+// concurrent caller); after that only kmers_hip_debug_knob() changes them.
+struct Knobs {
+    int y_atomics = 0;                    // KMERS_Y_ATOMICS: y for K >= 9 with plain global atomics
+    unsigned long long y_cap = 0;         // KMERS_Y_CAP: entries a slice's workgroup keeps before the overflow queue (0: default)
+    int force_wide = 0;                   // KMERS_FORCE_WIDE: 8-byte partition entries for K <= 8 too
+    int x_path = 0;                       // KMERS_X_PATH: 0 default, 1 "tables" (per-isoform LDS tables), 2 "rle" (no fused emit)
+    int old_pass0 = 0;                    // KMERS_X_OLD_PASS0: the position-ordered pass 0 of rounds 1-2
+    unsigned long long x_chunk_pos = 0;   // KMERS_X_CHUNK_POS: positions per device call of the file-level X calls (0: the limit)
+    int verbose = 0;                      // KMERS_VERBOSE
+};
+const Knobs &knobs();
+int set_knob(const char *name, long long value);   // "reset" re-reads the environment; 0 or -12
+
 size_t x_workspace_bytes(uint64_t n_pos, uint64_t n_rec, int K);
 
 size_t y_workspace_bytes(uint64_t n_pos, int K);  // 0 for K <= 8

@@ -70,8 +70,7 @@ struct StageClock {
     bool on;
     std::chrono::steady_clock::time_point t0;
     StageClock() : on(false), t0(std::chrono::steady_clock::now()) {
-        const char *e = getenv("KMERS_VERBOSE");
-        on = e && atoi(e) >= 2;
+        on = kk::knobs().verbose >= 2;
     }
     void lap(const char *what) {
         if (!on) return;
@@ -272,10 +271,8 @@ int build_files(int n_files, const char *fnames[], int K, int L, int mode, float
         n_rec_total = kmers_store_n_rec_total(g.s);
         // positions one device call takes; KMERS_X_CHUNK_POS lowers it (tests of the chunked route at small sizes)
         uint64_t chunk_pos = X_MAX_POS;
-        if (const char *e = getenv("KMERS_X_CHUNK_POS")) {
-            const long long v = atoll(e);
-            if (v > 0 && (uint64_t)v < X_MAX_POS) chunk_pos = (uint64_t)v;
-        }
+        if (const unsigned long long v = kk::knobs().x_chunk_pos)
+            if (v < X_MAX_POS) chunk_pos = v;
         if (n_pos <= chunk_pos && n_rec_total <= X_MAX_REC) {
             uint64_t nz = 0;
             if (int rc = build_store(g.s, K, max_size, data, row_ind, col_ind, &nz, clk)) return rc;
@@ -488,6 +485,8 @@ int kmers_hip_profile_get(int i, char *name, size_t name_cap, double *ms_total, 
     *calls = snap[(size_t)i].calls;
     return KMERS_OK;
 }
+
+int kmers_hip_debug_knob(const char *name, long long value) { return kk::set_knob(name, value); }
 
 // diagnostic builds only (-DKK_STAMPS): per-phase cycle sums of the scatter kernels; KMERS_ERR_BAD_ARG otherwise
 int kmers_hip_debug_stamps(unsigned long long *out16, int reset) { return kk::read_stamps(out16, reset != 0); }

@@ -2,7 +2,7 @@
 finishes in seconds: the HIP path is checked through properties that do not depend on the size, and through
 independent code paths that must agree bit for bit:
 
-  * X at K=8: 4-byte-entry path == 8-byte-entry path (KMERS_FORCE_WIDE); rows / columns ordered as the reference's CSR;
+  * X at K=8: 4-byte-entry path == 8-byte-entry path (knob force_wide); rows / columns ordered as the reference's CSR;
     every non-empty column sums to 1; row k is non-empty exactly when the k-mer occurs (y of the same file);
   * X at K=14 (four passes, 2^28 rows): same structural checks, and the whole == the interleave of two column shards;
   * y at K=8 (LDS tables), 12 (one partition pass, 2-byte payloads), 14 (two passes) == the plain global-atomics
@@ -59,7 +59,7 @@ def _csr_checks(torch, buf, nnz, n_rows, n_cols):
     return live
 
 
-def test_x8_full_size(full, monkeypatch):
+def test_x8_full_size(full, knob):
     import torch
     K, M = 8, 4 ** 8
     st = Store(full["iso"], MODE_X)
@@ -71,7 +71,7 @@ def test_x8_full_size(full, monkeypatch):
     live = _csr_checks(torch, buf, nnz, M, st.n_rec)
     assert int(live.sum()) > 0.99 * st.n_rec
     keep = {k: buf[k][:nnz].clone() if k != "row_ind" else buf[k].clone() for k in ("data", "col_ind", "row_ind")}
-    monkeypatch.setenv("KMERS_FORCE_WIDE", "1")                 # the 8-byte-entry path on the same input
+    knob("force_wide")                                          # the 8-byte-entry path on the same input
     assert ds.build_x(buf) == nnz
     for k in ("data", "col_ind"):
         assert torch.equal(buf[k][:nnz], keep[k]), k
@@ -111,7 +111,7 @@ def test_x14_full_size_and_shards(full):
 
 
 @pytest.mark.parametrize("K", [8, 12, 14])
-def test_y_full_size(full, K, monkeypatch):
+def test_y_full_size(full, K, knob):
     import torch
     st = Store(full["reads"], MODE_Y_FASTA)
     assert st.n_rec == 10_000_000
@@ -126,11 +126,11 @@ def test_y_full_size(full, K, monkeypatch):
         extra = int((y.long() - y12).sum())                 # 4 per read, plus 8-mers whose 12-mer runs into an N
         assert bool((y.long() >= y12).all()) and 4 * st.n_rec <= extra <= 4 * st.n_rec + total // 1000
     else:
-        monkeypatch.setenv("KMERS_Y_ATOMICS", "1")
+        knob("y_atomics")
         assert torch.equal(ds.count_y(K), y)
 
 
-def test_y12_one_hundred_million_simulated_reads(full, monkeypatch):
+def test_y12_one_hundred_million_simulated_reads(full, knob):
     """BASELINE.json configs[3] at its stated size."""
     import torch
     from kmers_amd.simulate_reads import simulate_reads_device
@@ -146,7 +146,7 @@ def test_y12_one_hundred_million_simulated_reads(full, monkeypatch):
     folded = y14.view(4 ** 12, 16).sum(1, dtype=torch.int64)      # every valid 14-mer starts with a valid 12-mer
     extra = y.long() - folded                                     # the two last 12-mers of a read + 12-mers stopped by an N
     assert bool((extra >= 0).all()) and 2 * N <= int(extra.sum()) == total - t14 <= 2 * N + total // 1000
-    monkeypatch.setenv("KMERS_Y_ATOMICS", "1")
+    knob("y_atomics")
     assert torch.equal(ds.count_y(12), y)
     # the sampled isoform ids and starts are the reference's stream: the histogram of the reads' first 12-mers follows
     assert info["theta_sampled"].shape[0] == len(info["lengths"]) and abs(float(info["theta_sampled"].sum()) - 1) < 1e-9

@@ -51,10 +51,10 @@ def test_x_random_vs_oracle(product, oracle, syn, K):
 
 
 @pytest.mark.parametrize("K", [2, 4, 5, 8])
-def test_x_wide_entries_for_small_k(product, oracle, syn, K, monkeypatch):
-    """K <= 8 normally runs on 4-byte entries; KMERS_FORCE_WIDE selects the 8-byte form (used for K >= 9 or more
+def test_x_wide_entries_for_small_k(product, oracle, syn, K, knob):
+    """K <= 8 normally runs on 4-byte entries; the force_wide knob selects the 8-byte form (used for K >= 9 or more
     than 2^24 records), which must give the same matrix."""
-    monkeypatch.setenv("KMERS_FORCE_WIDE", "1")
+    knob("force_wide")
     kmtest.assert_x_equal(product.x([syn["iso"], syn["uni"]], K), oracle.x([syn["iso"], syn["uni"]], K))
 
 
@@ -72,13 +72,13 @@ def test_x_first_and_last_row_in_one_round(product, oracle, tmp_path, K):
 
 
 @pytest.mark.parametrize("K,L,cat", [(8, 0, False), (13, 900, False), (6, 0, True), (11, 2000, True)])
-def test_x_in_record_ranges_above_the_per_call_limit(product, oracle, syn, K, L, cat, monkeypatch):
+def test_x_in_record_ranges_above_the_per_call_limit(product, oracle, syn, K, L, cat, knob):
     """An input of more positions than one device call indexes (2^32 - 65536) is built in contiguous record ranges that
-    are interleaved row by row on the host.  KMERS_X_CHUNK_POS lowers the limit so that the route runs here: 4 M
+    are interleaved row by row on the host.  The x_chunk_pos knob lowers the limit so that the route runs here: 4 M
     positions in ranges of at most ~300,000 (14 of them), one file per column in the cat mode (2 ranges)."""
     files = [syn["iso"], syn["uni"]]
     want = oracle.x(files, K, L, cat)
-    monkeypatch.setenv("KMERS_X_CHUNK_POS", "2000000" if cat else "300000")
+    knob("x_chunk_pos", 2000000 if cat else 300000)
     kmtest.assert_x_equal(product.x(files, K, L, cat), want)
     nnz = want[1].shape[0]
     assert product.x(files, K, L, cat, max_nz=nnz)[0] == 0
@@ -122,7 +122,7 @@ def test_y_small_workspace_chunks(oracle, syn, K):
 
 
 @pytest.mark.parametrize("K", [9, 12, 14, 16])
-def test_y_hot_bucket_overflow_queue(oracle, tmp_path, K, monkeypatch):
+def test_y_hot_bucket_overflow_queue(oracle, tmp_path, K, knob):
     """A slice with more entries than the per-workgroup cap hands the rest to the overflow kernel (several chunks,
     atomics into bins the slice's own workgroup also writes).  Poly-A reads put ~4e5 windows into one bin; the cap is
     forced down so that ordinary slices overflow too."""
@@ -141,14 +141,11 @@ def test_y_hot_bucket_overflow_queue(oracle, tmp_path, K, monkeypatch):
         assert rc == 0
         want = torch.from_numpy(want)
     else:
-        monkeypatch.setenv("KMERS_Y_ATOMICS", "1")
+        knob("y_atomics", 1)
         want = ds.count_y(K).cpu()
-        monkeypatch.delenv("KMERS_Y_ATOMICS")
-    for cap in ("1000", "7", None):
-        if cap is None:
-            monkeypatch.delenv("KMERS_Y_CAP")
-        else:
-            monkeypatch.setenv("KMERS_Y_CAP", cap)
+        knob("y_atomics", 0)
+    for cap in (1000, 7, 0):           # 0: the library's own cap
+        knob("y_cap", cap)
         got = ds.count_y(K)
         torch.cuda.synchronize()
         assert torch.equal(got.cpu(), want), cap
@@ -156,7 +153,7 @@ def test_y_hot_bucket_overflow_queue(oracle, tmp_path, K, monkeypatch):
 
 
 @pytest.mark.parametrize("K", [15, 16])
-def test_y_largest_k_partition_equals_atomics(syn, K, monkeypatch):
+def test_y_largest_k_partition_equals_atomics(syn, K, knob):
     """K = 15, 16 (4 / 16 GiB of bins: no oracle run at that size): the partition path against the plain
     global-atomics kernel on the GPU, plus the total against the host-side window count."""
     import torch
@@ -164,7 +161,7 @@ def test_y_largest_k_partition_equals_atomics(syn, K, monkeypatch):
     st = Store(syn["reads"], MODE_Y_FASTA)
     ds = st.to_device()
     a = ds.count_y(K)
-    monkeypatch.setenv("KMERS_Y_ATOMICS", "1")
+    knob("y_atomics")
     b = ds.count_y(K)
     torch.cuda.synchronize()
     assert torch.equal(a, b)
@@ -242,3 +239,37 @@ def test_one_giant_run(product, oracle, tmp_path):
     for K in (8, 12):
         kmtest.assert_x_equal(product.x([str(p)], K), oracle.x([str(p)], K))
         assert np.array_equal(product.y([str(p)], K)[1], oracle.y([str(p)], K)[1])
+
+
+@pytest.mark.parametrize("K", [2, 5, 8])
+def test_x_fused_emit_long_column_groups(product, oracle, tmp_path, K):
+    """K <= 8: the last partition pass writes the CSR arrays itself and closes a (k-mer, column) group that straddles a
+    tile by looking back / ahead over the column's entries (kernels.hip, "fused emit").  Records whose groups are
+    hundreds to tens of thousands of entries long -- repeats, poly-A, one long random record -- between short ones, so
+    that groups straddle tiles and wave chunks at every offset; all still below the length at which the library falls
+    back to the general path (that one is test_one_giant_run)."""
+    rng = np.random.default_rng(77 + K)
+    rnd = lambda n: "".join(rng.choice(list("ACGT"), n))
+    recs = []
+    for i in range(40):
+        recs.append(rnd(int(rng.integers(1, 400))))
+    recs += ["A" * 30_000, "ACGT" * 8_000, rnd(17), "AC" * 20_000 + rnd(3000), rnd(60_000), "T" * 9000 + "G" * 9000,
+             rnd(5), ("ACGTTGCA" * 3 + "N") * 2000, rnd(45_000) + "A" * 5000, rnd(300)]
+    for i in range(300):
+        recs.append(rnd(int(rng.integers(1, 900))))
+    p = tmp_path / "groups.fsa"
+    p.write_text("".join(f">r{i}\n{q}\n" for i, q in enumerate(recs)))
+    kmtest.assert_x_equal(product.x([str(p)], K), oracle.x([str(p)], K))
+
+
+def test_x_fused_emit_equals_the_run_length_path(product, oracle, syn, knob):
+    """K <= 8 has two ways from the partitioned instances to the CSR arrays: the fused emit of the last pass (default) and
+    k_scatter<entries> + k_rle (knob x_path = 2, also the fallback for records too long for the fused emit); pass 0 has
+    two kernels as well (old_pass0).  All of them against the oracle on the same input."""
+    files = [syn["iso"], syn["uni"]]
+    for K in (3, 6, 8):
+        want = oracle.x(files, K)
+        for x_path, old0 in ((0, 0), (2, 0), (2, 1), (0, 1)):
+            knob("x_path", x_path)
+            knob("old_pass0", old0)
+            kmtest.assert_x_equal(product.x(files, K), want)

@@ -1,7 +1,7 @@
 """The small-K X path (5 <= K <= 8: per-isoform LDS tables, kmers_amd/csrc/kernels.hip "X for 5 <= K <= 8") against the
 reference's golden fixtures and the oracle, bit for bit, through the drop-in C ABI.
 
-KMERS_X_PATH=tables selects the path (every test here sets it); without it the library takes the general partition
+The x_path knob (KMERS_X_PATH=tables in the environment) selects the path (every test here sets it); without it the library takes the general partition
 path, and the two must agree with the oracle and hence with each other."""
 import numpy as np
 import pytest
@@ -15,8 +15,8 @@ CASES = [c for c in kmtest.manifest() if c["kind"] == "x" and 5 <= c["K"] <= 8]
 
 
 @pytest.fixture(autouse=True)
-def _tables(monkeypatch):
-    monkeypatch.setenv("KMERS_X_PATH", "tables")
+def _tables(knob):
+    knob("x_path", 1)
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
@@ -62,10 +62,10 @@ def test_reads_as_records(product, oracle, syn):
         kmtest.assert_x_equal(product.x([syn["reads"]], K), oracle.x([syn["reads"]], K))
 
 
-def test_both_paths_on_the_same_input(product, oracle, syn, monkeypatch):
+def test_both_paths_on_the_same_input(product, oracle, syn, knob):
     want = oracle.x([syn["big"]], 7)
     kmtest.assert_x_equal(product.x([syn["big"]], 7), want)       # the tables (set by the fixture)
-    monkeypatch.delenv("KMERS_X_PATH")
+    knob("x_path", 0)
     kmtest.assert_x_equal(product.x([syn["big"]], 7), want)       # the default: the partition path
 
 
@@ -92,12 +92,12 @@ def test_counts_beyond_the_entry_field_and_long_isoforms(product, oracle, tmp_pa
         kmtest.assert_x_equal(product.x([str(p)], K), oracle.x([str(p)], K))
 
 
-def test_a_count_that_wraps_the_table_falls_back(product, oracle, tmp_path, capfd, monkeypatch):
+def test_a_count_that_wraps_the_table_falls_back(product, oracle, tmp_path, capfd, knob):
     """70,000 windows of one k-mer in one isoform do not fit a 16-bit field: the library notices and rebuilds X on the
     general path; the result is the reference's either way."""
     p = tmp_path / "wrap.fsa"
     p.write_text(">a\nACGTACGTAC\n>b\n" + "A" * 70_007 + "CGT\n>c\nTTTTTTTTTTGA\n")
-    monkeypatch.setenv("KMERS_VERBOSE", "1")
+    knob("verbose", 1)
     kmtest.assert_x_equal(product.x([str(p)], 8), oracle.x([str(p)], 8))
     assert "rebuilt on the general path" in capfd.readouterr().err
     p.write_text(">a\nACGTACGTAC\n>b\n" + "A" * 65_542 + "CGT\n>c\nTTTTTTTTTTGA\n")     # 65,535 windows: the largest that fits

@@ -17,6 +17,8 @@ assert st.n_pos > 2 ** 31
 ds = st.to_device()
 K = 8
 buf = ds.x_buffers(K, st.n_windows(K))
+from kmers_amd import _lib as _l
+_knob = _l.handle().kmers_hip_debug_knob
 nnz = ds.build_x(buf)
 row = buf["row_ind"]
 assert int(row[-1]) == nnz and bool((row[1:] >= row[:-1]).all())
@@ -28,19 +30,19 @@ assert float((sums[live] - 1).abs().max()) < 1e-4
 print("x8 narrow ok: nnz", nnz, "> 2^31:", nnz > 2 ** 31, flush=True)
 keep_row = row.clone()
 chk = (int(col.sum()), float(buf["data"][:nnz].double().sum()))
-os.environ["KMERS_FORCE_WIDE"] = "1"
+_knob(b"force_wide", 1)
 assert ds.build_x(buf) == nnz
 assert torch.equal(buf["row_ind"], keep_row)
 assert (int(buf["col_ind"][:nnz].sum()), float(buf["data"][:nnz].double().sum())) == chk
-del os.environ["KMERS_FORCE_WIDE"]
+_knob(b"force_wide", 0)
 print("x8 wide == narrow (row pointer equal, column and value checksums equal)", flush=True)
 del buf
 torch.cuda.empty_cache()
 sy = Store(path, MODE_Y_FASTA).to_device()
 y = sy.count_y(12)
-os.environ["KMERS_Y_ATOMICS"] = "1"
+_knob(b"y_atomics", 1)
 assert torch.equal(sy.count_y(12), y)
-del os.environ["KMERS_Y_ATOMICS"]
+_knob(b"y_atomics", 0)
 print("y12 partition (2 chunks) == atomics; total", int(y.sum(dtype=torch.int64)), flush=True)
 os.remove(path)
 print("big check ok", round(time.time() - t0), "s")
