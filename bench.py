@@ -52,6 +52,7 @@ def parse(argv=None):
     ap.add_argument("--reads", type=int, default=100_000_000, help="simulated reads of the y workloads, over ALL ranks")
     ap.add_argument("--model-reads", type=int, default=10_000_000, help="reads of the g workloads (per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the wall time of the file-level drop-in call")
     ap.add_argument("--no-concat", action="store_true", help="N > 1: skip the host concatenation of the X shards")
     ap.add_argument("--cache", default=os.environ.get("KMERS_BENCH_CACHE", "/tmp/kmers_bench"))
     args = ap.parse_args(argv)
@@ -234,45 +235,142 @@ def roofline(table, kernel_bytes, path_bytes, ms_per_step, steps, workload, defa
             "algorithmic_bytes": int(kernel_bytes[dom[0]])}
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def host_threads():
+    """Threads this process may use: the box's CPU share (OMP_NUM_THREADS is set to it there), else all CPUs."""
+    for var in ("KMERS_BENCH_THREADS", "OMP_NUM_THREADS"):
+        v = os.environ.get(var, "")
+        if v.isdigit() and int(v) > 0:
+            return int(v)
+    return os.cpu_count() or 1
+
+
+def sample_file(args, path, max_bytes):
+    """A prefix of a FASTA file that ends at a record boundary (the bounded CPU sample), cached beside it."""
+    if os.path.getsize(path) <= max_bytes:
+        return path
+    out = f"{path}.first{max_bytes}"
+    if not os.path.exists(out):
+        with open(path, "rb") as f:
+            buf = f.read(max_bytes)
+        cut = buf.rfind(b"\n>")
+        tmp = f"{out}.tmp{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(buf[:cut + 1])
+        os.replace(tmp, out)
+    return out
+
+
 def cpu_baseline(args, K, kind_x):
     """The reference library itself (oracle/_ref, built in the build container from /root/reference/src) -- or, when that
-    build is absent, the oracle port -- timed on the host cores: X on the FULL transcriptome file of the GPU run, y on a
-    bounded sample of reads drawn from it the same way."""
+    build is absent, the oracle port -- timed on the host cores as SURVEY.md section 8d asks: with all the threads this
+    process may use AND with KMER_NUM_THREADS=1 (the reference's knob, src/libkmers.cpp:50-52), median over up to 5 calls
+    each, on a bounded sample of the GPU run's own input (a prefix of the transcriptome file / reads drawn from it the same
+    way) sized so that both legs together take some tens of seconds."""
     from tests import kmtest
     from kmers_amd.store import MODE_X, MODE_Y_FASTA, Store
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libkmers_ref.so")
-    cores = min(16, os.cpu_count() or 1)
-    os.environ["KMER_NUM_THREADS"] = str(cores)
+    threads = host_threads()
     if os.path.exists(ref_so):
         lib, kind = kmtest.Lib(ref_so, "", hip=False), "reference"
     else:
-        lib, kind, cores = kmtest.load_oracle(), "port", 1
+        lib, kind, threads = kmtest.load_oracle(), "port", 1
+    if kind_x:
+        full = transcriptome_file(args)[0]
+        path = sample_file(args, full, 60_000_000)
+        path1 = sample_file(args, full, 15_000_000)        # the single-thread leg: a quarter of it, so that 5 calls fit
+        what = (f"the first {os.path.getsize(path) / 1e6:.0f} MB of the GPU run's transcriptome file"
+                if path != full else "the transcriptome file of the GPU run")
+    else:
+        n_reads = max(1000, min(500_000, args.reads // 200))
+        path = transcriptome_file(args, with_reads=n_reads)[1]
+        path1 = transcriptome_file(args, with_reads=max(1000, n_reads // 4))[1]
+        what = f"{n_reads} reads of 100 bp drawn from the same transcriptome"
+
+    def n_windows(p):
+        st = Store(p, MODE_X if kind_x else MODE_Y_FASTA)
+        try:
+            return st.n_windows(K)
+        finally:
+            st.close()
+
+    windows, windows1 = n_windows(path), n_windows(path1)
+
+    def one_call(path):
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        saved = os.dup(1)
+        sys.stdout.flush()
+        os.dup2(devnull, 1)                  # the reference prints phase timings to stdout
+        try:
+            t0 = time.perf_counter()
+            rc = (lib.x([path], K) if kind_x else lib.y([path], K))[0]
+            dt = time.perf_counter() - t0
+        finally:
+            os.dup2(saved, 1)
+            os.close(devnull)
+            os.close(saved)
+        assert rc == 0, rc
+        return dt
+
+    def leg(path, n_threads, budget_s):
+        os.environ["KMER_NUM_THREADS"] = str(n_threads)
+        times = [one_call(path)]
+        while len(times) < 5 and sum(times) + times[0] < budget_s:
+            times.append(one_call(path))
+        return float(np.median(times)), len(times)
+
+    saved_threads = os.environ.get("KMER_NUM_THREADS")
+    try:
+        t_all, n_all = leg(path, threads, 8.0)
+        t_one, n_one = leg(path1, 1, 12.0)
+    finally:
+        if saved_threads is None:
+            os.environ.pop("KMER_NUM_THREADS", None)
+        else:
+            os.environ["KMER_NUM_THREADS"] = saved_threads
+    return {"value": windows / t_all, "unit": "k-mers/s", "cores": threads, "kind": kind,
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
+            "single_thread": {"value": windows1 / t_one, "calls": n_one, "median_s": round(t_one, 3), "kmers": windows1},
+            "calls": n_all, "median_s": round(t_all, 3),
+            "sample": f"{what} ({windows} k-mers), {'fasta_to_kmers_csr' if kind_x else 'fasta_count_kmers'} at K={K}, "
+                      f"file in page cache; value = median of {n_all} calls with KMER_NUM_THREADS={threads}, "
+                      f"single_thread = median of {n_one} calls with KMER_NUM_THREADS=1 on a quarter of that sample"}
+
+
+def e2e_record(args, K, kind_x):
+    """Wall time of the drop-in call users make (kmerexpr/libkmers.py:130-184 / :86-105): file in the page cache -> the
+    caller's numpy arrays, with the library's own stage split.  Never `value`: it includes host parsing and PCIe."""
+    from kmers_amd import _lib, libkmers
     if kind_x:
         path = transcriptome_file(args)[0]
-        what = f"the full transcriptome of the GPU run ({args.records} isoforms / {args.bases / 1e6:.0f} Mbases)"
+        call, what = "fasta_to_kmers_csr", f"the transcriptome file of the GPU run ({os.path.getsize(path) / 1e6:.0f} MB)"
+        fn = lambda: libkmers.fasta_to_kmers_csr(path, K)
     else:
         n_reads = max(1000, min(2_000_000, args.reads // 50))
         path = transcriptome_file(args, with_reads=n_reads)[1]
-        what = f"{n_reads} reads of 100 bp drawn from the same transcriptome"
-    st = Store(path, MODE_X if kind_x else MODE_Y_FASTA)
-    windows = st.n_windows(K)
-    st.close()
-    devnull = os.open(os.devnull, os.O_WRONLY)
-    saved = os.dup(1)
-    sys.stdout.flush()
-    os.dup2(devnull, 1)                  # the reference prints phase timings to stdout
-    try:
+        call, what = "fasta_count_kmers", f"{n_reads} reads of 100 bp as a FASTA file ({os.path.getsize(path) / 1e6:.0f} MB)"
+        fn = lambda: libkmers.fasta_count_kmers(path, K)
+    fn()                                      # page cache, pinned pools, code objects
+    times, stages = [], None
+    for _ in range(3):
         t0 = time.perf_counter()
-        rc = (lib.x([path], K) if kind_x else lib.y([path], K))[0]
-        dt = time.perf_counter() - t0
-    finally:
-        os.dup2(saved, 1)
-        os.close(devnull)
-        os.close(saved)
-    assert rc == 0, rc
-    return {"value": windows / dt, "unit": "k-mers/s", "cores": cores, "kind": kind,
-            "sample": f"{what}, one call of {'fasta_to_kmers_csr' if kind_x else 'fasta_count_kmers'} at K={K}, "
-                      f"{dt:.1f} s wall, file in page cache"}
+        fn()
+        times.append(time.perf_counter() - t0)
+        if times[-1] == min(times):
+            stages = _lib.last_call_stages()
+    return {"call": call, "input": what, "wall_s": round(min(times), 4), "calls": len(times),
+            "stages_ms": {k: round(v, 2) for k, v in (stages or {}).items()},
+            "host_threads": host_threads()}
 
 
 # ------------------------------------------------------------------------------------------------ the workloads
@@ -322,6 +420,9 @@ def run_x(ctx, K, tag):
         "k_hist_entries": es * E,
         "k_scatter<entries>": 2 * es * E,
         "k_rle": es * E + 12 * nnz + 8 * (M + 1),
+        # K <= 8, round 3: the last pass writes the CSR arrays itself (k_heads_hist counts heads, k_emit partitions + emits)
+        "k_heads_hist": es * E,
+        "k_emit": es * E + 12 * nnz + 4 * n_rec,
         # the small-K table path (KMERS_X_PATH=tables): entries are the nnz distinct (k-mer, isoform) pairs
         "k_dd<hist>": n_pos * 3 / 8 + 8 * (n_rec + 1),
         "k_dd<scatter>": n_pos * 3 / 8 + 8 * (n_rec + 1) + 4 * nnz,
@@ -329,14 +430,16 @@ def run_x(ctx, K, tag):
     }
     if "k_dd<hist>" in {r[0] for r in table}:
         kernel_bytes["k_hist_entries"] = 4 * nnz
-    default_size = (args.records, args.bases) == (170_000, 400_000_000) and ctx.world == 1
+    full_size = (args.records, args.bases) == (170_000, 400_000_000)
+    default_size = full_size and ctx.world == 1
     gbs = path_bytes / (ms * 1e-3) / 1e9
     out = {
         "metric": METRIC, "value": windows_all * args.steps / dt_max, "unit": "k-mers/s", "n_gpus": ctx.world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "strong" if ctx.world > 1 else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"transcriptome_to_x K={K}: {int(rec_all)} records / {bases_all / 1e6:.0f} Mbases "
-                               f"({'BASELINE.json configs[1]' if tag == 'x8' else 'configs[2]' if tag == 'x14' else tag}"
+        "config": {"workload": f"transcriptome_to_x K={K}: {int(rec_all)} records / {bases_all / 1e6:.0f} Mbases ("
+                               + (("BASELINE.json configs[1]" if tag == "x8" else "BASELINE.json configs[2]" if tag == "x14"
+                                   else tag) if full_size else f"{tag}, NOT a BASELINE.json size")
                                + (f"; the one transcriptome in {ctx.world} column shards, one per GPU)" if ctx.world > 1 else ")"),
                    "K": K, "records": int(rec_all), "bases": int(bases_all), "kmers": int(windows_all),
                    "nnz": int(nnz_all), "rank0": {"records": n_rec, "bases": n_bases, "valid_instances": E, "nnz": nnz},
@@ -374,6 +477,14 @@ def run_y(ctx, K, tag):
 
     dt, table = timed(ctx, step)
     E = int(counts.sum(dtype=torch.int64).item())      # valid windows of ALL reads (the histogram is all-reduced)
+    allreduce_ms = None
+    if ctx.world > 1:                    # the collective alone, timed apart (after the steps) so the curve says where time goes
+        ctx.fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.all_reduce_dev(counts)
+        ctx.fence()
+        allreduce_ms = ctx.all_max_sum((time.perf_counter() - t0) / args.steps * 1e3)[0]
     dt_max, windows_all, reads_all = ctx.all_max_sum(dt, windows, n_reads)
     del y_ws
     torch.cuda.empty_cache()
@@ -395,14 +506,16 @@ def run_y(ctx, K, tag):
     n_chunks = max(1, -(-n_pos // (1 << 31)))
     # chunked stores launch every kernel once per chunk: bytes per launch
     kernel_bytes = {k: v / n_chunks for k, v in kernel_bytes.items()}
-    default_size = (args.records, args.bases, args.reads) == (170_000, 400_000_000, 100_000_000) and ctx.world == 1
+    full_size = (args.records, args.bases, args.reads) == (170_000, 400_000_000, 100_000_000)
+    default_size = full_size and ctx.world == 1
     gbs = path_bytes / (ms * 1e-3) / 1e9
     return {
         "metric": METRIC, "value": windows_all * args.steps / dt_max, "unit": "k-mers/s", "n_gpus": ctx.world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "strong" if ctx.world > 1 else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"reads->y K={K}: {int(reads_all)} simulated 100 bp reads "
-                               f"({'BASELINE.json configs[3]' if tag == 'y12' else tag}"
+        "config": {"workload": f"reads->y K={K}: {int(reads_all)} simulated 100 bp reads ("
+                               + (("BASELINE.json configs[3]" if tag == "y12" else tag) if full_size
+                                  else f"{tag}, NOT a BASELINE.json size")
                                + (f"; {ctx.world} shards, histogram all-reduced over RCCL)" if ctx.world > 1 else ")"),
                    "K": K, "reads": int(reads_all), "kmers": int(windows_all), "reads_rank0": n_reads,
                    "chunks_per_step": n_chunks, "parallelism": f"read-shards{ctx.world}"},
@@ -410,6 +523,7 @@ def run_y(ctx, K, tag):
         "path": {"algorithmic_bytes": int(path_bytes), "bytes_per_kmer": round(path_bytes / max(windows, 1), 3),
                  "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)},
         "kernels_ms": {r[0]: round(r[1] / args.steps, 4) for r in table},
+        **({"allreduce_ms": round(allreduce_ms, 4), "allreduce_bytes": 4 * M} if allreduce_ms is not None else {}),
     }
 
 
@@ -511,6 +625,11 @@ def run_workload(ctx, tag):
             out["cpu_baseline"] = cpu_baseline(ctx.args, K, kind == "x")
         except Exception as e:  # the baseline must never hide the GPU number
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    if out is not None and ctx.world == 1 and not ctx.args.no_e2e:
+        try:
+            out["e2e"] = e2e_record(ctx.args, K, kind == "x")
+        except Exception as e:
+            out["e2e"] = {"wall_s": None, "error": repr(e)}
     return out
 
 

@@ -155,6 +155,12 @@ void kmers_hip_profile_enable(int on);
 int kmers_hip_profile_count(void);
 int kmers_hip_profile_get(int i, char *name, size_t name_cap, double *ms_total, uint64_t *calls);
 
+/* Wall time of the stages of the most recent file-level call (fasta_to_kmers_csr, fasta_count_kmers, ...) of this
+ * process, as "stage name=milliseconds;" pairs in call order: host ingest, H2D + device buffers, the GPU stage, D2H into
+ * the caller's arrays.  The counterpart of the reference's Timer printouts (src/libkmers.cpp:34-41, :93, :123, :166);
+ * KMERS_VERBOSE=2 also prints them to stderr. */
+int kmers_last_call_stages(char *buf, size_t cap);
+
 /* Path switches for tests and same-run A/B measurements (process-wide; never needed in production).  The library reads
  * the environment variables of the same meaning ONCE, at its first use in the process (KMERS_Y_ATOMICS, KMERS_Y_CAP,
  * KMERS_FORCE_WIDE, KMERS_X_PATH=tables|rle, KMERS_X_OLD_PASS0, KMERS_X_CHUNK_POS, KMERS_VERBOSE); afterwards only this call

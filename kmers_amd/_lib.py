@@ -125,6 +125,7 @@ def handle():
     lib.kmers_hip_model_read.restype, lib.kmers_hip_model_read.argtypes = C.c_int, [vp, C.c_int, vp]
     lib.kmers_hip_model_logp_grad.restype = C.c_int
     lib.kmers_hip_model_logp_grad.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_double), vp, vp]
+    lib.kmers_last_call_stages.restype, lib.kmers_last_call_stages.argtypes = C.c_int, [C.c_char_p, C.c_size_t]
     lib.kmers_hip_debug_knob.restype, lib.kmers_hip_debug_knob.argtypes = C.c_int, [C.c_char_p, C.c_longlong]
     lib.kmers_hip_profile_enable.restype, lib.kmers_hip_profile_enable.argtypes = None, [C.c_int]
     lib.kmers_hip_profile_count.restype, lib.kmers_hip_profile_count.argtypes = C.c_int, []
@@ -147,6 +148,18 @@ def profile_table():
         ms, calls = C.c_double(0), C.c_uint64(0)
         if lib.kmers_hip_profile_get(i, name, 64, C.byref(ms), C.byref(calls)) == 0:
             out.append((name.value.decode(), ms.value, int(calls.value)))
+    return out
+
+
+def last_call_stages():
+    """{stage: ms} of the most recent file-level call (kmers_last_call_stages)."""
+    buf = C.create_string_buffer(1024)
+    handle().kmers_last_call_stages(buf, 1024)
+    out = {}
+    for item in buf.value.decode().split(";"):
+        if "=" in item:
+            k, v = item.rsplit("=", 1)
+            out[k] = out.get(k, 0.0) + float(v)
     return out
 
 

@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
@@ -64,19 +66,28 @@ struct DevBuf {
     }
 };
 
-// KMERS_VERBOSE=2: wall time of the stages of a file-level call on stderr (the reference prints its phase times to
-// stdout, src/libkmers.cpp:34-41, :86-168; nothing is printed by default here)
+// Wall time of the stages of a file-level call: always kept for kmers_last_call_stages() (bench.py's `e2e` record), and
+// printed to stderr with KMERS_VERBOSE=2 (the reference prints its phase times to stdout, src/libkmers.cpp:34-41, :86-168;
+// nothing is printed by default here).
+std::mutex g_stage_mu;
+std::string g_last_stages;
 struct StageClock {
-    bool on;
+    bool print;
     std::chrono::steady_clock::time_point t0;
-    StageClock() : on(false), t0(std::chrono::steady_clock::now()) {
-        on = kk::knobs().verbose >= 2;
-    }
+    std::string acc;
+    StageClock() : print(kk::knobs().verbose >= 2), t0(std::chrono::steady_clock::now()) {}
     void lap(const char *what) {
-        if (!on) return;
         const auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "libkmers: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        char line[128];
+        snprintf(line, sizeof line, "%s=%.3f;", what, ms);
+        acc += line;
+        if (print) fprintf(stderr, "libkmers: %-28s %8.3f ms\n", what, ms);
         t0 = t1;
+    }
+    ~StageClock() {
+        std::lock_guard<std::mutex> lk(g_stage_mu);
+        g_last_stages = acc;
     }
 };
 
@@ -483,6 +494,13 @@ int kmers_hip_profile_get(int i, char *name, size_t name_cap, double *ms_total, 
     snprintf(name, name_cap, "%s", snap[(size_t)i].name.c_str());
     *ms_total = snap[(size_t)i].ms;
     *calls = snap[(size_t)i].calls;
+    return KMERS_OK;
+}
+
+int kmers_last_call_stages(char *buf, size_t cap) {
+    if (!buf || !cap) return KMERS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    snprintf(buf, cap, "%s", g_last_stages.c_str());
     return KMERS_OK;
 }
 
