@@ -3517,6 +3517,20 @@ static dim3 xs0_grid(uint32_t n_tiles8, int bnt) {
     return dim3(nbt < (uint32_t)XS0_BLOCKS ? nbt : (uint32_t)XS0_BLOCKS);
 }
 
+// uint64 -> uint32, for the file-level calls' device-to-host copy: column numbers and row pointers of one device call fit
+// 32 bits, and PCIe (not HBM) bounds that copy; the host widens them again while it moves them into the caller's arrays.
+__global__ void k_narrow64(const uint64_t *in, uint32_t *out, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (uint32_t)in[i];
+}
+int narrow64(const uint64_t *d_in, uint32_t *d_out, uint64_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    const uint64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_narrow64, dim3((uint32_t)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, d_in, d_out, n);
+    KK_CHECK(hipGetLastError());
+    return 0;
+}
+
 int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid, size_t valid_words, const uint64_t *d_rec_start,
             uint64_t n_pos, uint64_t n_rec, uint64_t first_col, int K, float *d_data, uint64_t *d_col_ind, uint64_t *d_row_ind,
             uint64_t max_nz, void *d_ws, size_t ws_bytes, uint64_t *nnz_out, hipStream_t s) {

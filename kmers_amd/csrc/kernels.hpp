@@ -55,4 +55,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
             uint64_t n_pos, uint64_t n_rec, uint64_t first_col, int K, float *d_data, uint64_t *d_col_ind, uint64_t *d_row_ind,
             uint64_t max_nz, void *d_ws, size_t ws_bytes, uint64_t *nnz_out, hipStream_t s);
 
+// d_out[i] = (uint32_t)d_in[i] (asynchronous on s): the file-level calls send 32-bit indices over PCIe
+int narrow64(const uint64_t *d_in, uint32_t *d_out, uint64_t n, hipStream_t s);
+
 }  // namespace kk

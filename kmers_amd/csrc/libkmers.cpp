@@ -21,6 +21,8 @@
 #include <string>
 #include <vector>
 
+#include <sys/mman.h>
+
 #include <hip/hip_runtime_api.h>
 
 namespace {
@@ -95,18 +97,43 @@ struct StageClock {
 // buffers at a fraction of the link rate; here 32 MiB chunks land in two pinned buffers by DMA while the host threads
 // move the previous chunk to its destination with `sink(dst offset, pinned src, bytes)` (a memcpy, or the "+=" of the
 // y calls).  Leaves the stream idle.
+// The two pinned chunks and their events are kept for the life of the process (pinning 64 MiB costs milliseconds, and a
+// file-level X call makes three of these copies); concurrent callers take turns.
+struct PinPool {
+    std::mutex mu;
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int dev = -1;
+    static constexpr size_t chunk = (size_t)32 << 20;
+    int ready() {  // with mu held
+        int d = -1;
+        if (hipGetDevice(&d) != hipSuccess) return KMERS_ERR_HIP;
+        if (pin[0] && d == dev) return KMERS_OK;
+        for (int i = 0; i < 2; ++i) {
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            if (pin[i]) (void)hipHostFree(pin[i]);
+            pin[i] = nullptr, ev[i] = nullptr;
+        }
+        for (int i = 0; i < 2; ++i)
+            if (hipHostMalloc(&pin[i], chunk, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                return KMERS_ERR_HIP;
+            }
+        dev = d;
+        return KMERS_OK;
+    }
+};
+PinPool g_pins;
+
 template <class Sink>
 int d2h_chunks(const void *d_src, size_t bytes, hipStream_t s, const Sink &sink) {
     if (bytes == 0) return KMERS_OK;
-    const size_t chunk = (size_t)32 << 20;
-    void *pin[2] = {nullptr, nullptr};
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    int rc = KMERS_OK;
-    for (int i = 0; i < 2 && rc == KMERS_OK; ++i) {
-        if (hipHostMalloc(&pin[i], std::min(chunk, bytes), hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess)
-            rc = KMERS_ERR_HIP;
-    }
+    std::lock_guard<std::mutex> lk(g_pins.mu);
+    int rc = g_pins.ready();
+    const size_t chunk = PinPool::chunk;
+    void *const *pin = g_pins.pin;
+    hipEvent_t *ev = g_pins.ev;
     const size_t n_chunks = (bytes + chunk - 1) / chunk;
     auto issue = [&](size_t c) {
         const size_t off = c * chunk, n = std::min(chunk, bytes - off);
@@ -129,10 +156,6 @@ int d2h_chunks(const void *d_src, size_t bytes, hipStream_t s, const Sink &sink)
         fprintf(stderr, "libkmers: HIP error in the device-to-host copy\n");
     }
     (void)hipStreamSynchronize(s);
-    for (int i = 0; i < 2; ++i) {
-        if (ev[i]) (void)hipEventDestroy(ev[i]);
-        if (pin[i]) (void)hipHostFree(pin[i]);
-    }
     return rc;
 }
 
@@ -241,9 +264,50 @@ int build_store(const kmers_store *st, int K, uint64_t max_size, float *data, ui
     }
     if (rc) return rc;
     clk.lap("build X (GPU)");
-    if (int e = d2h_copy(row_ind, d_row.p, (M + 1) * 8, s)) return e;
+    // PCIe bounds this stage (config 2: 4.6 GB of CSR): indices travel as 32-bit values -- narrowed on the device into the
+    // workspace, which is free again, widened by the host threads as they move each chunk into the caller's uint64
+    // arrays -- a third fewer bytes on the link.  (Every value fits: nnz and the column numbers of one call are < 2^32.)
+    auto d2h_widen = [&](uint64_t *dst, const uint32_t *d_src32, uint64_t n) {
+        return d2h_chunks(d_src32, n * 4, s, [&](size_t off, const char *src, size_t nb) {
+            uint64_t *out = dst + off / 4;
+            const uint32_t *v = (const uint32_t *)src;
+            kmers::parallel_for(nb / 4, (size_t)1 << 18, [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; ++i) out[i] = v[i];
+            });
+        });
+    };
+    // The caller's arrays are usually fresh (numpy.zeros: untouched pages), so this copy also pays their first-touch
+    // page faults; asking for huge pages first makes those 512 times fewer where the system allows it.
+    auto huge = [](void *p, size_t bytes) {
+        const uintptr_t a = ((uintptr_t)p + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1), e = ((uintptr_t)p + bytes) & ~(uintptr_t)((2u << 20) - 1);
+        if (e > a) (void)madvise((void *)a, e - a, MADV_HUGEPAGE);
+    };
     if (nz) {
-        if (int e = d2h_copy(col_ind, d_col.p, nz * 8, s)) return e;
+        huge(data, nz * 4);
+        huge(col_ind, nz * 8);
+    }
+    huge(row_ind, (M + 1) * 8);
+    const bool cols_fit = kmers_store_first_rec(st) + n_rec <= 0xFFFFFFFFull;
+    const size_t col32_bytes = (size_t)((nz * 4 + 255) / 256 * 256), row32_bytes = (size_t)(M + 1) * 4;
+    const bool narrow_cols = cols_fit && nz && col32_bytes <= ws_bytes;
+    const bool narrow_rows = (narrow_cols ? col32_bytes : 0) + row32_bytes <= ws_bytes;
+    uint32_t *d_col32 = d_ws.as<uint32_t>();
+    uint32_t *d_row32 = (uint32_t *)((char *)d_ws.p + (narrow_cols ? col32_bytes : 0));
+    if (narrow_cols)
+        if (int e = kk::narrow64(d_col.as<uint64_t>(), d_col32, nz, s)) return e;
+    if (narrow_rows)
+        if (int e = kk::narrow64(d_row.as<uint64_t>(), d_row32, M + 1, s)) return e;
+    if (narrow_rows) {
+        if (int e = d2h_widen(row_ind, d_row32, M + 1)) return e;
+    } else {
+        if (int e = d2h_copy(row_ind, d_row.p, (M + 1) * 8, s)) return e;
+    }
+    if (nz) {
+        if (narrow_cols) {
+            if (int e = d2h_widen(col_ind, d_col32, nz)) return e;
+        } else {
+            if (int e = d2h_copy(col_ind, d_col.p, nz * 8, s)) return e;
+        }
         if (int e = d2h_copy(data, d_data.p, nz * 4, s)) return e;
     }
     clk.lap("D2H into the host arrays");
