@@ -165,7 +165,7 @@ int kmers_last_call_stages(char *buf, size_t cap);
  * the environment variables of the same meaning ONCE, at its first use in the process (KMERS_Y_ATOMICS, KMERS_Y_CAP,
  * KMERS_FORCE_WIDE, KMERS_X_PATH=tables|rle, KMERS_X_OLD_PASS0, KMERS_X_CHUNK_POS, KMERS_VERBOSE); afterwards only this call
  * changes them: name = "y_atomics", "y_cap", "force_wide", "x_path" (0 default, 1 tables, 2 rle), "old_pass0",
- * "x_chunk_pos", "verbose", or "reset" (re-read the environment).  Returns 0, or KMERS_ERR_BAD_ARG for an unknown name.
+ * "x_chunk_pos", "verbose", "wide14" (KMERS_X_WIDE14), or "reset" (re-read the environment).  Returns 0, or KMERS_ERR_BAD_ARG for an unknown name.
  * No counterpart in the reference. */
 int kmers_hip_debug_knob(const char *name, long long value);
 

@@ -458,15 +458,17 @@ __device__ __forceinline__ uint32_t runs_of(uint32_t v, int K) {
     return r & (r >> (K - s));
 }
 
+template <int BITS>
 __global__ __launch_bounds__(HB_NT) void k_hist_bases(BasesArgs a, uint32_t *tilehist, uint32_t n_tiles, uint32_t *rec_total) {
-    __shared__ uint32_t hs[HB_NW][RADIX];
+    constexpr int BINS = 1 << BITS;  // digit 0 = the low BITS bits of the k-mer id
+    __shared__ uint32_t hs[HB_NW][BINS];
     const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
     uint32_t *const h = hs[w];
     const uint32_t n_waves = gridDim.x * HB_NW, wave = blockIdx.x * HB_NW + w;
     const int K = a.K;
     const uint32_t ksh = 32u - 2u * (uint32_t)K;
 #pragma unroll
-    for (int i = 0; i < RADIX / 64; ++i) h[lane + 64 * i] = 0u;
+    for (int i = 0; i < BINS / 64; ++i) h[lane + 64 * i] = 0u;
     for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
         uint32_t rec_base = __builtin_amdgcn_readfirstlane(a.tile_cb[tile]);  // record starts strictly before the group
         uint32_t carry = 0;  // valid windows of record rec_base - 1 seen in this tile and not yet added (wave-uniform)
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(HB_NT) void k_hist_bases(BasesArgs a, uint32_t *til
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const uint32_t top = j ? __builtin_amdgcn_alignbit(x.b0, x.b1, 32u - 2u * (uint32_t)j) : x.b0;
-                if ((okm >> j) & 1u) atomicAdd(&h[(top >> ksh) & 255u], 1u);
+                if ((okm >> j) & 1u) atomicAdd(&h[(top >> ksh) & (uint32_t)(BINS - 1)], 1u);
             }
             // ---- valid windows per record
             const uint32_t call = (uint32_t)__popc(okm);
@@ -536,9 +538,9 @@ __global__ __launch_bounds__(HB_NT) void k_hist_bases(BasesArgs a, uint32_t *til
         // the wave's table -> the tile's row; zeroed for the next tile
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < RADIX / 64; ++i) {
+        for (int i = 0; i < BINS / 64; ++i) {
             const uint32_t v = h[lane + 64 * i];
-            tilehist[(uint64_t)tile * RADIX + lane + 64 * i] = v;
+            tilehist[(uint64_t)tile * BINS + lane + 64 * i] = v;
             h[lane + 64 * i] = 0u;
         }
     }
@@ -672,10 +674,12 @@ __global__ __launch_bounds__(BNT) void k_yscatter(BasesArgs a, const uint32_t *t
 
 // Later-pass histogram over stored entries.  Persistent: workgroup b walks a contiguous range of tiles and loads
 // tile t+1 while tile t is counted (two LDS tables: one is zeroed while the other is filled); tiles past the entry count get zeros.
-template <class ET>
+template <class ET, int BITS = 8>
 __global__ __launch_bounds__(NT) void k_hist_entries(const ET *ent, const uint32_t *p_count, int shift, uint32_t *tilehist,
                                                      uint32_t n_tiles) {
     constexpr bool NARROW = sizeof(ET) == 4;
+    constexpr int RADIX = 1 << BITS;  // (shadows the 256 of the file scope: this kernel's number of bins)
+    static_assert(RADIX <= NT && (!NARROW || BITS == 8), "one thread per bin when a tile's row is written");
     __shared__ uint32_t h[2][NW][RADIX];
     const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
     const uint32_t E = *p_count;
@@ -704,7 +708,7 @@ __global__ __launch_bounds__(NT) void k_hist_entries(const ET *ent, const uint32
             if constexpr (NARROW)
                 d = (uint32_t)e[j] >> 24;
             else
-                d = (entry_key((u64)e[j]) >> shift) & 255u;
+                d = (entry_key((u64)e[j]) >> shift) & (uint32_t)(RADIX - 1);
             if (i < E) atomicAdd(&hc[w][d], 1u);
         }
         if (tile + 1 < t1) load_tile(tile + 1);  // e[] is free again
@@ -961,6 +965,114 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
     KK_STAMP_END(FROM_BASES ? 0 : 8);
 }
 
+// Later passes of the 8-byte-entry path (K >= 9) with digits of up to 9 bits: the same stable scatter as k_scatter<false>
+// (OR-mask match per (wave, digit), LDS staging, coalesced runs out), 2^BITS bins.  Round 3: K = 13, 14 take three
+// passes (9 + 9 + 8 and 10 + 9 + 9 bits) instead of four of 8 bits, K = 9 two instead of three -- a pass costs a
+// histogram plus a scatter whatever its digit width, as long as two workgroups still fit a CU: with 512 bins the
+// per-(wave, digit) counters are 16-bit (a count is at most 1024, a tile-local slot below 8192) and the 64-bit match
+// words (32 KB) still alias the 64 KB entry staging; 1024 bins would need all of it and one workgroup per CU.
+// `bits` <= BITS is the width of this pass's digit (a narrower last digit leaves bins empty).
+template <int BITS>
+__global__ __launch_bounds__(NT, 4) void k_scatter_wide(const u64 *in, const uint32_t *p_count, int shift, int bits,
+                                                        const uint32_t *tilebase, u64 *out) {
+    constexpr int BINS = 1 << BITS;
+    using CT = typename std::conditional<(BITS > 8), uint16_t, uint32_t>::type;
+    static_assert(BINS <= NT, "one thread per digit in the scan");
+    __shared__ __attribute__((aligned(16))) u64 sent[TILE];
+    __shared__ CT wcnt[NW][BINS];
+    static_assert(NW * BINS * 8 <= TILE * 8, "match masks alias the entry staging");
+    __shared__ uint32_t gadj[BINS];
+    __shared__ uint32_t stmp[NW];
+    const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
+    const uint32_t E = *p_count;
+    const uint32_t nt = (uint32_t)(((uint64_t)E + TILE - 1) / TILE);
+    const uint32_t per = (nt + gridDim.x - 1) / gridDim.x;
+    const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < nt) ? t0 + per : nt;
+    if (t0 >= t1) return;
+    u64 *const smask = sent;
+    u64 e[IPT];
+    auto load_tile = [&](uint32_t t) {
+        const uint32_t c0 = t * TILE + w * WCHUNK;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const uint64_t i = (uint64_t)c0 + j * 64 + lane;
+            e[j] = (i < E) ? in[i] : 0ull;
+        }
+    };
+    load_tile(t0);
+    uint32_t gb = (tid < BINS) ? tilebase[(uint64_t)t0 * BINS + tid] : 0u;
+    for (uint32_t tile = t0; tile < t1; ++tile) {
+        const uint64_t base = (uint64_t)tile * TILE;
+        for (uint32_t i = tid; i < NW * BINS; i += NT) {
+            (&wcnt[0][0])[i] = 0;
+            smask[i] = 0ull;
+        }
+        lds_sync();
+        uint32_t wl = w * WCHUNK + lane;
+        asm volatile("" : "+v"(wl));
+        const uint32_t n_valid = (uint32_t)((E - base < TILE) ? E - base : TILE);
+        CT *const wrow = &wcnt[w][0];
+        u64 *const wmask = &smask[w * BINS];
+        uint32_t rank[IPT];
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const bool ok = wl + j * 64 < n_valid;
+            const uint32_t d = __builtin_amdgcn_ubfe(entry_key(e[j]), (uint32_t)shift, (uint32_t)bits);
+            u64 m = 0;
+            uint32_t before = 0;
+            if (ok) {
+                atomicOr(&wmask[d], 1ull << lane);
+                m = wmask[d];
+                before = wrow[d];
+            }
+            const uint32_t m_lo = (uint32_t)m, m_hi = (uint32_t)(m >> 32);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+            rank[j] = ok ? (before + below) : NONE;
+            if (ok && below == 0) {
+                wrow[d] = (CT)(before + (uint32_t)__popc(m_lo) + (uint32_t)__popc(m_hi));
+                wmask[d] = 0ull;
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_sync();
+        uint32_t dtot = 0;
+        uint32_t wc[NW];
+        if (tid < BINS) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                wc[i] = dtot;
+                dtot += wcnt[i][tid];
+            }
+        }
+        uint32_t tile_count;
+        const uint32_t dstart = block_excl_scan<true>(dtot, stmp, tile_count);
+        if (tid < BINS) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) wcnt[i][tid] = (CT)(dstart + wc[i]);
+            gadj[tid] = gb - dstart;
+            if (tile + 1 < t1) gb = tilebase[(uint64_t)(tile + 1) * BINS + tid];
+        }
+        lds_sync();
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            if (rank[j] != NONE) {
+                const uint32_t d = __builtin_amdgcn_ubfe(entry_key(e[j]), (uint32_t)shift, (uint32_t)bits);
+                sent[(uint32_t)wrow[d] + rank[j]] = e[j];
+            }
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tile + 1 < t1) load_tile(tile + 1);
+        lds_sync();
+        for (uint32_t i = tid; i < tile_count; i += NT) {
+            const u64 v = sent[i];
+            const uint32_t d = __builtin_amdgcn_ubfe(entry_key(v), (uint32_t)shift, (uint32_t)bits);
+            out[gadj[d] + i] = v;
+        }
+        lds_sync();
+    }
+}
+
 // X pass 0, round 3: the order INSIDE one column does not matter.
 //
 // The later passes are stable and the run-length reduce only asks that the instances of one (k-mer, column) end up
@@ -975,15 +1087,29 @@ __global__ __launch_bounds__(NT, 4) void k_scatter(BasesArgs a, const ET *in, co
 // starts in s + 1 sweeps.  Waves stay ordered through their private counters (scan over the waves, as before).
 // Tiles are BNT * 16 positions = BNT / 512 rows of the (8192-position) tile histogram: in the scanned table the rows of
 // one digit follow each other, so the first row's base serves the whole tile.
-template <class ET, int BNT>
+// BITS = width of digit 0 (the low bits of the k-mer id): 8 for the 4-byte entries of K <= 8; 8, 9 or 10 for the 8-byte
+// entries of K >= 9 (see k_scatter_wide).  Above 8 bits the per-(wave, digit) counters are packed two to a word (a wave
+// has 1024 windows: a count fits 16 bits, and so does a tile-local slot), and at 10 bits the staged entry is 4 + 2 bytes
+// instead of 8 -- (id >> 10) << 14 | column relative to the tile's first, and the digit beside it; a tile of 8192
+// positions holds at most 8192 record starts, and 2 K - 10 <= 18 bits are left of the id for K <= 14 -- so that the
+// 1024 counters still leave room for two workgroups per CU.
+template <class ET, int BNT, int BITS>
 __global__ __launch_bounds__(BNT) void k_xscatter0(BasesArgs a, const uint32_t *tilebase, uint32_t n_tiles8, ET *out) {
     constexpr bool NARROW = sizeof(ET) == 4;
+    constexpr int BINS = 1 << BITS;
+    constexpr bool PACKED = BITS > 8, COMPACT = BITS == 10;
     constexpr int BNW = BNT / 64, BTILE = BNT * 16, TPB = BTILE / TILE;
+    constexpr int CW = PACKED ? BINS / 2 : BINS;  // counter words per wave
     static_assert(BNT % NT == 0, "a tile is a whole number of histogram rows");
-    __shared__ __attribute__((aligned(16))) ET sent[BTILE];
-    __shared__ uint8_t saux[NARROW ? BTILE : 4];  // narrow: the digit of every staged entry (the entry holds the OTHER byte)
-    __shared__ uint32_t wcnt[BNW][RADIX];
-    __shared__ uint32_t gadj[RADIX], swave[BNW], sdig[RADIX / 64];
+    static_assert(!NARROW || BITS == 8, "4-byte entries keep ONE other byte of the id");
+    static_assert(!COMPACT || (BTILE == 8192 && !NARROW), "the compact staging holds a 14-bit relative column");
+    static_assert(CW <= BNT, "one counter word per thread in the scan");
+    using ST = typename std::conditional<COMPACT, uint32_t, ET>::type;
+    __shared__ __attribute__((aligned(16))) ST sent[BTILE];
+    __shared__ uint8_t saux[NARROW ? BTILE : 4];      // narrow: the digit of every staged entry (the entry holds the OTHER byte)
+    __shared__ uint16_t saux16[COMPACT ? BTILE : 2];  // compact: the same, 10 bits
+    __shared__ uint32_t wcnt[BNW][CW];
+    __shared__ uint32_t gadj[BINS], swave[BNW], sdig[BNW];
     const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
     const uint32_t nbt = (n_tiles8 + TPB - 1) / TPB;
     const uint32_t per = (nbt + gridDim.x - 1) / gridDim.x;
@@ -994,13 +1120,35 @@ __global__ __launch_bounds__(BNT) void k_xscatter0(BasesArgs a, const uint32_t *
         const uint32_t fw = ((g >> 1) < a.valid_words) ? a.rec_flags[g >> 1] : 0u;
         return (g & 1) ? (fw >> 16) : (fw & 0xFFFFu);
     };
+    // the scanned histogram row of a tile: thread t takes bin t, or (packed) bins 2 t and 2 t + 1
+    auto fetch_base = [&](uint32_t tile, uint32_t &b0, uint32_t &b1) {
+        const uint32_t *row = tilebase + (uint64_t)tile * TPB * BINS;
+        if constexpr (PACKED) {
+            if (tid < (uint32_t)CW) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(row + 2 * tid);
+                b0 = v.x, b1 = v.y;
+            }
+        } else {
+            if (tid < (uint32_t)BINS) b0 = row[tid];
+        }
+    };
     WordWindows nx = word_fetch(a, (uint64_t)t0 * BNT + tid);
     uint32_t nfl = fetch_flags((uint64_t)t0 * BNT + tid);
     uint32_t ncb = a.tile_cb[(uint64_t)t0 * TPB];
-    uint32_t gb = (tid < RADIX) ? tilebase[(uint64_t)t0 * TPB * RADIX + tid] : 0u;
+    uint32_t gb0 = 0, gb1 = 0;
+    fetch_base(t0, gb0, gb1);
     uint32_t *const wrow = &wcnt[w][0];
+    // rank of a window inside (wave, digit) = what the returning atomic on the wave's counter hands out
+    auto take_rank = [&](uint32_t d) -> uint32_t {
+        if constexpr (PACKED) {
+            const uint32_t sh = (d & 1u) * 16u;
+            return (atomicAdd(&wrow[d >> 1], 1u << sh) >> sh) & 0xFFFFu;
+        } else {
+            return atomicAdd(&wrow[d], 1u);
+        }
+    };
     for (uint32_t tile = t0; tile < t1; ++tile) {
-        for (uint32_t i = tid; i < BNW * RADIX; i += BNT) (&wcnt[0][0])[i] = 0;
+        for (uint32_t i = tid; i < BNW * CW; i += BNT) (&wcnt[0][0])[i] = 0;
         const WordWindows x = nx;
         const uint32_t fl = nfl, cb_tile = ncb;
         if (tile + 1 < t1) {
@@ -1018,13 +1166,14 @@ __global__ __launch_bounds__(BNT) void k_xscatter0(BasesArgs a, const uint32_t *
 #pragma unroll
         for (int i = 0; i < BNW; ++i)
             if ((uint32_t)i < w) before_w += swave[i];
-        const uint32_t lc0 = finc - nf;                 // starts in this wave's chunk before the word
-        const uint32_t col0 = cb_tile + before_w + lc0 - 1u;  // column of a position of this word that follows no start in it
-        const uint32_t okm = runs_of(x.v, K) & 0xFFFFu;   // bit j: window j of the word is a k-mer
-        uint32_t rank[16];  // bits 0..15 the rank inside (wave, digit), bits 16..23 the digit; NONE = no k-mer
+        const uint32_t lc0 = finc - nf;                    // starts in this wave's chunk before the word
+        const uint32_t rel0 = before_w + lc0;              // starts in this TILE before the word
+        const uint32_t colm1 = cb_tile - 1u;               // column of a position in front of the tile's first start
+        const uint32_t okm = runs_of(x.v, K) & 0xFFFFu;    // bit j: window j of the word is a k-mer
+        uint32_t rank[16];  // bits 0..15 the rank inside (wave, digit), bits 16..25 the digit; NONE = no k-mer
         auto digit_of = [&](int j) -> uint32_t {
             const uint32_t top = j ? __builtin_amdgcn_alignbit(x.b0, x.b1, 32u - 2u * (uint32_t)j) : x.b0;
-            return (top >> (32u - 2u * (uint32_t)K)) & 255u;
+            return (top >> (32u - 2u * (uint32_t)K)) & (uint32_t)(BINS - 1);
         };
 #ifdef XS0_NOPHASE  // diagnostic builds (wrong results)
         if (true) {
@@ -1036,7 +1185,7 @@ __global__ __launch_bounds__(BNT) void k_xscatter0(BasesArgs a, const uint32_t *
                 rank[j] = NONE;
                 if ((okm >> j) & 1u) {
                     const uint32_t d = digit_of(j);
-                    rank[j] = atomicAdd(&wrow[d], 1u) | (d << 16);
+                    rank[j] = take_rank(d) | (d << 16);
                 }
             }
         } else {  // column after column (sweep ph takes the windows that follow exactly ph starts of the wave's chunk)
@@ -1052,69 +1201,97 @@ __global__ __launch_bounds__(BNT) void k_xscatter0(BasesArgs a, const uint32_t *
                     const uint32_t lc = lc0 + (uint32_t)__popc(flo & ((2u << j) - 1u));
                     if (((okm >> j) & 1u) && lc == ph) {
                         const uint32_t top = j ? __builtin_amdgcn_alignbit(b0, b1, 32u - 2u * (uint32_t)j) : b0;
-                        const uint32_t d = (top >> (32u - 2u * (uint32_t)K)) & 255u;
-                        rank[j] = atomicAdd(&wrow[d], 1u) | (d << 16);
+                        const uint32_t d = (top >> (32u - 2u * (uint32_t)K)) & (uint32_t)(BINS - 1);
+                        rank[j] = take_rank(d) | (d << 16);
                     }
                 }
             }
         }
         lds_sync();
-        // digit d: exclusive scan of the per-wave counts over the waves, then of the tile totals over the digits
-        uint32_t dtot = 0;
-        if (tid < RADIX) {
+        // exclusive scan of the per-wave counts over the waves (per digit), then of the tile totals over the digits:
+        // afterwards the wave's counter of digit d holds the tile-local slot of the wave's first entry of d
+        uint32_t t_lo = 0, t_hi = 0;  // tile totals of this thread's digit(s)
+        if (tid < (uint32_t)CW) {
 #pragma unroll
             for (int i = 0; i < BNW; ++i) {
                 const uint32_t c = wcnt[i][tid];
-                wcnt[i][tid] = dtot;
-                dtot += c;
+                if constexpr (PACKED) {
+                    wcnt[i][tid] = t_lo | (t_hi << 16);
+                    t_lo += c & 0xFFFFu;
+                    t_hi += c >> 16;
+                } else {
+                    wcnt[i][tid] = t_lo;
+                    t_lo += c;
+                }
             }
         }
+        const uint32_t dtot = t_lo + t_hi;
         const uint32_t dinc = wave_incl_scan(dtot);
-        if (tid < RADIX && lane == 63) sdig[w] = dinc;
+        if (lane == 63) sdig[w] = dinc;
         lds_sync();
         uint32_t dbase = 0, tile_count = 0;
 #pragma unroll
-        for (int i = 0; i < RADIX / 64; ++i) {
+        for (int i = 0; i < BNW; ++i) {
             const uint32_t t = sdig[i];
             if ((uint32_t)i < w) dbase += t;
             tile_count += t;
         }
-        if (tid < RADIX) {
-            const uint32_t dstart = dbase + dinc - dtot;
+        if (tid < (uint32_t)CW) {
+            const uint32_t s_lo = dbase + dinc - dtot, s_hi = s_lo + t_lo;
 #pragma unroll
-            for (int i = 0; i < BNW; ++i) wcnt[i][tid] += dstart;
-            gadj[tid] = gb - dstart;
-            if (tile + 1 < t1) gb = tilebase[(uint64_t)(tile + 1) * TPB * RADIX + tid];
+            for (int i = 0; i < BNW; ++i) wcnt[i][tid] += PACKED ? (s_lo | (s_hi << 16)) : s_lo;
+            if constexpr (PACKED) {
+                gadj[2 * tid] = gb0 - s_lo;
+                gadj[2 * tid + 1] = gb1 - s_hi;
+            } else {
+                gadj[tid] = gb0 - s_lo;
+            }
         }
+        if (tile + 1 < t1) fetch_base(tile + 1, gb0, gb1);
         lds_sync();
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             if (rank[j] != NONE) {
                 const uint32_t top = j ? __builtin_amdgcn_alignbit(x.b0, x.b1, 32u - 2u * (uint32_t)j) : x.b0;
                 const uint32_t key = top >> (32u - 2u * (uint32_t)K);
-                const uint32_t col = col0 + (uint32_t)__popc(fl & ((2u << j) - 1u));
-                const uint32_t d = (rank[j] >> 16) & 255u;
-                const uint32_t slot = wrow[d] + (rank[j] & 0xFFFFu);
+                const uint32_t rel = rel0 + (uint32_t)__popc(fl & ((2u << j) - 1u));  // starts of the tile at or before the window
+                const uint32_t d = (rank[j] >> 16) & (uint32_t)(BINS - 1);
+                uint32_t start;
+                if constexpr (PACKED)
+                    start = (wrow[d >> 1] >> ((d & 1u) * 16u)) & 0xFFFFu;
+                else
+                    start = wrow[d];
+                const uint32_t slot = start + (rank[j] & 0xFFFFu);
                 if constexpr (NARROW) {
-                    sent[slot] = ((key >> 8) << 24) | col;
+                    sent[slot] = ((key >> 8) << 24) | (colm1 + rel);
                     saux[slot] = (uint8_t)d;
+                } else if constexpr (COMPACT) {
+                    sent[slot] = ((key >> BITS) << 14) | rel;   // rel <= 8192
+                    saux16[slot] = (uint16_t)d;
                 } else {
-                    sent[slot] = make_entry(key, col);
+                    sent[slot] = make_entry(key, colm1 + rel);
                 }
             }
         }
         lds_sync();
         for (uint32_t i = tid; i < tile_count; i += BNT) {
-            const ET v = sent[i];
+            const ST v = sent[i];
             uint32_t d;
-            if constexpr (NARROW)
+            ET o;
+            if constexpr (NARROW) {
                 d = saux[i];
-            else
-                d = entry_key((u64)v) & 255u;
+                o = v;
+            } else if constexpr (COMPACT) {
+                d = saux16[i];
+                o = make_entry(((v >> 14) << BITS) | d, colm1 + (v & 0x3FFFu));
+            } else {
+                d = entry_key((u64)v) & (uint32_t)(BINS - 1);
+                o = v;
+            }
 #ifdef XS0_NOSTORE  // diagnostic builds (wrong results)
-            if (v == (ET)0x12345678u)
+            if (d == 0x12345678u)
 #endif
-            out[gadj[d] + i] = v;
+            out[gadj[d] + i] = o;
         }
         lds_sync();
     }
@@ -1356,8 +1533,9 @@ __global__ __launch_bounds__(YS_NT) void k_count_y_overflow(const ET *ent, int t
 // i.e. the exclusive scan in digit-major order, computed as 256 column scans plus a 256-value scan of the totals.
 // Three launches: sums per chunk of CSCAN_TILES tiles; one workgroup turns them into chunk bases; apply.
 
-constexpr int CSCAN_TILES = 64, CSCAN_SEG = 4;
+constexpr int CSCAN_TILES = 64;
 
+template <int RADIX>  // (the bins of the pass: 256, or 512 / 1024 for the wide passes of K >= 9)
 __global__ __launch_bounds__(RADIX) void k_cscan_reduce(const uint32_t *hist, uint32_t n_tiles, uint32_t *chunk_sums) {
     const uint32_t d = threadIdx.x, c = blockIdx.x;
     const uint32_t t0 = c * CSCAN_TILES, t1 = (t0 + CSCAN_TILES < n_tiles) ? t0 + CSCAN_TILES : n_tiles;
@@ -1367,8 +1545,10 @@ __global__ __launch_bounds__(RADIX) void k_cscan_reduce(const uint32_t *hist, ui
     chunk_sums[(uint64_t)c * RADIX + d] = s;
 }
 
-// One workgroup of RADIX * CSCAN_SEG threads: thread (seg, d) owns a quarter of digit d's chunks.
-__global__ __launch_bounds__(RADIX *CSCAN_SEG) void k_cscan_mid(uint32_t *chunk_sums, uint32_t n_chunks, uint32_t *p_total) {
+// One workgroup of 1024 threads = RADIX * CSCAN_SEG: thread (seg, d) owns a CSCAN_SEG-th of digit d's chunks.
+template <int RADIX>
+__global__ __launch_bounds__(1024) void k_cscan_mid(uint32_t *chunk_sums, uint32_t n_chunks, uint32_t *p_total) {
+    constexpr int CSCAN_SEG = 1024 / RADIX;
     __shared__ uint32_t seg_sum[CSCAN_SEG][RADIX];
     __shared__ uint32_t dbase[RADIX];
     __shared__ uint32_t stmp[RADIX * CSCAN_SEG / 64];
@@ -1417,6 +1597,7 @@ __global__ __launch_bounds__(RADIX *CSCAN_SEG) void k_cscan_mid(uint32_t *chunk_
 
 // regions (may be null): regions[d] = position of the first entry of digit d = tile 0's scanned row, regions[256] = the
 // entry count *p_count (no launch of its own).
+template <int RADIX>
 __global__ __launch_bounds__(RADIX) void k_cscan_apply(uint32_t *hist, uint32_t n_tiles, const uint32_t *chunk_base, uint32_t *regions,
                                                        const uint32_t *p_count) {
     const uint32_t d = threadIdx.x, c = blockIdx.x;
@@ -3035,6 +3216,7 @@ static void read_knobs_locked() {
     k.old_pass0 = getenv("KMERS_X_OLD_PASS0") != nullptr;
     k.x_chunk_pos = num("KMERS_X_CHUNK_POS");
     k.verbose = (int)num("KMERS_VERBOSE");
+    k.wide14 = getenv("KMERS_X_WIDE14") != nullptr;
     g_knobs = k;
     g_knobs_read = true;
 }
@@ -3056,6 +3238,7 @@ int set_knob(const char *name, long long value) {
     else if (n == "old_pass0") g_knobs.old_pass0 = value != 0;
     else if (n == "x_chunk_pos") g_knobs.x_chunk_pos = value > 0 ? (unsigned long long)value : 0;
     else if (n == "verbose") g_knobs.verbose = (int)value;
+    else if (n == "wide14") g_knobs.wide14 = value != 0;
     else return -12;
     return 0;
 }
@@ -3150,6 +3333,26 @@ int read_stamps(unsigned long long *, bool) { return -12; }
 static inline uint32_t cscan_chunks(uint32_t n_tiles) { return (n_tiles + CSCAN_TILES - 1) / CSCAN_TILES; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Digits of the 8-byte-entry path (K >= 9, or K <= 8 with more than 2^24 records), least significant first.  Pass 0
+// (k_xscatter0) takes 8, 9 or 10 bits, a later pass (k_scatter_wide) up to 9.
+struct WidePlan {
+    int n;
+    int bits[4];
+};
+static WidePlan wide_plan(int K, bool classic) {
+    const int total = 2 * K;
+    WidePlan p{(total + 7) / 8, {8, 8, 8, 8}};
+    if (classic) return p;  // rounds 1-2: ceil(2K / 8) passes of 8 bits
+    if (K == 9) p = WidePlan{2, {9, 9, 0, 0}};     // config 2's transcriptome: 8.94 -> 7.81 ms
+    if (K == 13) p = WidePlan{3, {9, 9, 8, 0}};    // 11.77 -> 10.61 ms
+    // K = 14 as 10 + 9 + 9 was built and measured (knob wide14 = 1 selects it; bit-exact): 11.87 ms against 11.98 for
+    // four 8-bit passes -- the two 9-bit passes save 1.1 ms, the 10-bit pass 0 (64-byte runs out of the tile, compact
+    // staging) gives 0.94 of it back and the 1024-bin scan 0.16: not worth a second code path by default.
+    if (K == 14 && knobs().wide14) p = WidePlan{3, {10, 9, 9, 0}};
+    return p;
+}
+static int wide_max_bits(int K) { return K == 14 ? 10 : ((K == 9 || K == 13) ? 9 : 8); }  // (whatever the knobs say)
+
 struct XLayout {
     uint32_t n_tiles;
     uint32_t dd_rows;        // histogram rows of the small-K path: its tiles + one per workgroup + the all-zero last row
@@ -3170,7 +3373,8 @@ static XLayout x_layout(uint64_t n_pos, uint64_t n_rec, int K) {
     // all-zero rows behind them), the small-K table path's
     uint32_t rows = l.n_tiles + RADIX + 2;
     if (l.dd_rows > rows) rows = l.dd_rows;
-    l.hist_len = (uint64_t)RADIX * rows;
+    const uint64_t max_bins = 1ull << wide_max_bits(K);
+    l.hist_len = max_bins * rows;
     l.scan_blocks = cscan_chunks(rows);
     l.esc_cap = (uint32_t)(emax < (1u << 22) ? emax : (1u << 22));
     const uint64_t M = 1ull << (2 * K);
@@ -3188,7 +3392,7 @@ static XLayout x_layout(uint64_t n_pos, uint64_t n_rec, int K) {
     l.off_entA = take(emax * 8);
     l.off_entB = take(emax * 8);
     l.off_hist = take(l.hist_len * 4);
-    l.off_blocksums = take((size_t)l.scan_blocks * RADIX * 4);
+    l.off_blocksums = take((size_t)l.scan_blocks * max_bins * 4);
     l.off_total = take((n_rec ? n_rec : 1) * 4);
     l.off_flags = take(((emax + 31) / 32 + 4) * 4);
     l.off_tilecb = take(((size_t)l.n_tiles + 2) * 4);
@@ -3215,14 +3419,25 @@ size_t x_workspace_bytes(uint64_t n_pos, uint64_t n_rec, int K) { return x_layou
     } while (0)
 
 // hist[n_tiles][RADIX] -> bases in place; *p_total = number of entries.  chunk_sums: cscan_chunks(n_tiles) * RADIX words.
-static int scan_tilehist(uint32_t *hist, uint32_t n_tiles, uint32_t *chunk_sums, uint32_t *p_total, hipStream_t s,
-                         uint32_t *regions = nullptr, const uint32_t *p_count = nullptr) {
+template <int BINS>
+static int scan_tilehist_bins(uint32_t *hist, uint32_t n_tiles, uint32_t *chunk_sums, uint32_t *p_total, hipStream_t s,
+                              uint32_t *regions, const uint32_t *p_count) {
     const uint32_t nc = cscan_chunks(n_tiles);
-    hipLaunchKernelGGL(k_cscan_reduce, dim3(nc), dim3(RADIX), 0, s, (const uint32_t *)hist, n_tiles, chunk_sums);
-    hipLaunchKernelGGL(k_cscan_mid, dim3(1), dim3(RADIX * CSCAN_SEG), 0, s, chunk_sums, nc, p_total);
-    hipLaunchKernelGGL(k_cscan_apply, dim3(nc), dim3(RADIX), 0, s, hist, n_tiles, (const uint32_t *)chunk_sums, regions, p_count);
+    hipLaunchKernelGGL(k_cscan_reduce<BINS>, dim3(nc), dim3(BINS), 0, s, (const uint32_t *)hist, n_tiles, chunk_sums);
+    hipLaunchKernelGGL(k_cscan_mid<BINS>, dim3(1), dim3(1024), 0, s, chunk_sums, nc, p_total);
+    hipLaunchKernelGGL(k_cscan_apply<BINS>, dim3(nc), dim3(BINS), 0, s, hist, n_tiles, (const uint32_t *)chunk_sums, regions, p_count);
     KK_CHECK(hipGetLastError());
     return 0;
+}
+// hist rows of 2^bits counts (8, 9 or 10 bits); regions (256 bins only) as before
+static int scan_tilehist(uint32_t *hist, uint32_t n_tiles, uint32_t *chunk_sums, uint32_t *p_total, hipStream_t s,
+                         uint32_t *regions = nullptr, const uint32_t *p_count = nullptr, int bits = 8) {
+    switch (bits) {
+        case 8: return scan_tilehist_bins<256>(hist, n_tiles, chunk_sums, p_total, s, regions, p_count);
+        case 9: return scan_tilehist_bins<512>(hist, n_tiles, chunk_sums, p_total, s, nullptr, nullptr);
+        case 10: return scan_tilehist_bins<1024>(hist, n_tiles, chunk_sums, p_total, s, nullptr, nullptr);
+    }
+    return -12;
 }
 
 // ---- y workspace (K >= 9): entries of one chunk of tiles, the tile histogram and its scan, regions, scalars
@@ -3585,7 +3800,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     const dim3 grid(l.n_tiles), block(NT);
     const dim3 pgrid(l.n_tiles < (uint32_t)PERSIST_BLOCKS ? l.n_tiles : (uint32_t)PERSIST_BLOCKS);
     const dim3 hgrid(l.n_tiles < (uint32_t)KK_HIST_BLOCKS ? l.n_tiles : (uint32_t)KK_HIST_BLOCKS);
-    const int n_pass = (2 * K + 7) / 8;
+    const int n_pass = (2 * K + 7) / 8;   // (4-byte entries: one or two passes of 8 bits)
     const bool old_pass0 = kn.old_pass0;  // knob: A-B runs against the position-ordered pass 0
 
     // K <= 8 and at most 2^24 records: 4-byte entries (digit byte << 24 | column), else 8-byte (k-mer id << 32 | column)
@@ -3594,9 +3809,17 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     const uint32_t *c_hist = hist, *c_E = &scal[0];
 
     // pass 0: packed bases -> instances partitioned by the lowest digit
-    hipLaunchKernelGGL(k_hist_bases, dim3(l.n_tiles < 4u * HB_BLOCKS ? (l.n_tiles + HB_NW - 1) / HB_NW : (uint32_t)HB_BLOCKS), dim3(HB_NT), 0, s, a, hist, l.n_tiles, total);
+    const WidePlan plan = wide_plan(K, old_pass0 || kn.x_path == 2);   // (8-byte entries only)
+    const int bits0 = narrow ? 8 : plan.bits[0];
+    const dim3 hb_grid(l.n_tiles < 4u * HB_BLOCKS ? (l.n_tiles + HB_NW - 1) / HB_NW : (uint32_t)HB_BLOCKS);
+    if (bits0 == 8)
+        hipLaunchKernelGGL(k_hist_bases<8>, hb_grid, dim3(HB_NT), 0, s, a, hist, l.n_tiles, total);
+    else if (bits0 == 9)
+        hipLaunchKernelGGL(k_hist_bases<9>, hb_grid, dim3(HB_NT), 0, s, a, hist, l.n_tiles, total);
+    else
+        hipLaunchKernelGGL(k_hist_bases<10>, hb_grid, dim3(HB_NT), 0, s, a, hist, l.n_tiles, total);
     pt.mark("k_hist_bases");
-    if (int rc = scan_tilehist(hist, l.n_tiles, bsum, &scal[0], s, regs0, c_E)) return rc;
+    if (int rc = scan_tilehist(hist, l.n_tiles, bsum, &scal[0], s, bits0 == 8 ? regs0 : nullptr, c_E, bits0)) return rc;
     pt.mark("k_scan");
     const uint32_t *final_regions = regs0;
     if (narrow) {
@@ -3605,7 +3828,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
             hipLaunchKernelGGL((k_scatter<true, uint32_t>), pgrid, block, 0, s, a, (const uint32_t *)nullptr, c_E, 0, c_hist, l.n_tiles,
                                ei, (const uint32_t *)nullptr);
         else
-            hipLaunchKernelGGL((k_xscatter0<uint32_t, XS0_NT_NARROW>), xs0_grid(l.n_tiles, XS0_NT_NARROW), dim3(XS0_NT_NARROW), 0, s, a,
+            hipLaunchKernelGGL((k_xscatter0<uint32_t, XS0_NT_NARROW, 8>), xs0_grid(l.n_tiles, XS0_NT_NARROW), dim3(XS0_NT_NARROW), 0, s, a,
                                c_hist, l.n_tiles, ei);
         pt.mark("k_scatter<bases>");
         if (kn.x_path != 2) {  // knob: A-B runs against k_scatter<entries> + k_rle
@@ -3658,21 +3881,36 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         if (old_pass0)
             hipLaunchKernelGGL((k_scatter<true, u64>), pgrid, block, 0, s, a, (const u64 *)nullptr, c_E, 0, c_hist, l.n_tiles, ei,
                                (const uint32_t *)nullptr);
-        else
-            hipLaunchKernelGGL((k_xscatter0<u64, XS0_NT_WIDE>), xs0_grid(l.n_tiles, XS0_NT_WIDE), dim3(XS0_NT_WIDE), 0, s, a, c_hist,
+        else if (bits0 == 8)
+            hipLaunchKernelGGL((k_xscatter0<u64, XS0_NT_WIDE, 8>), xs0_grid(l.n_tiles, XS0_NT_WIDE), dim3(XS0_NT_WIDE), 0, s, a, c_hist,
                                l.n_tiles, ei);
+        else if (bits0 == 9)
+            hipLaunchKernelGGL((k_xscatter0<u64, XS0_NT_WIDE, 9>), xs0_grid(l.n_tiles, XS0_NT_WIDE), dim3(XS0_NT_WIDE), 0, s, a, c_hist,
+                               l.n_tiles, ei);
+        else
+            hipLaunchKernelGGL((k_xscatter0<u64, 512, 10>), xs0_grid(l.n_tiles, 512), dim3(512), 0, s, a, c_hist, l.n_tiles, ei);
         pt.mark("k_scatter<bases>");
-        for (int p = 1; p < n_pass; ++p) {
-            const int shift = 8 * p;
-            hipLaunchKernelGGL(k_hist_entries<u64>, grid, block, 0, s, (const u64 *)ei, c_E, shift, hist, l.n_tiles);
+        int shift = bits0;
+        for (int p = 1; p < plan.n; ++p) {
+            const int bits = plan.bits[p];
+            if (bits == 9)
+                hipLaunchKernelGGL((k_hist_entries<u64, 9>), grid, block, 0, s, (const u64 *)ei, c_E, shift, hist, l.n_tiles);
+            else
+                hipLaunchKernelGGL((k_hist_entries<u64, 8>), grid, block, 0, s, (const u64 *)ei, c_E, shift, hist, l.n_tiles);
             pt.mark("k_hist_entries");
-            if (int rc = scan_tilehist(hist, l.n_tiles, bsum, &scal[4], s)) return rc;
+            if (int rc = scan_tilehist(hist, l.n_tiles, bsum, &scal[4], s, nullptr, nullptr, bits)) return rc;
             pt.mark("k_scan");
-            hipLaunchKernelGGL((k_scatter<false, u64>), pgrid, block, 0, s, a, (const u64 *)ei, c_E, shift, c_hist, l.n_tiles, eo,
-                               (const uint32_t *)nullptr);
+            if (old_pass0 || kn.x_path == 2)   // (rounds 1-2: 8-bit digits only)
+                hipLaunchKernelGGL((k_scatter<false, u64>), pgrid, block, 0, s, a, (const u64 *)ei, c_E, shift, c_hist, l.n_tiles, eo,
+                                   (const uint32_t *)nullptr);
+            else if (bits == 9)
+                hipLaunchKernelGGL(k_scatter_wide<9>, pgrid, block, 0, s, (const u64 *)ei, c_E, shift, bits, c_hist, eo);
+            else
+                hipLaunchKernelGGL(k_scatter_wide<8>, pgrid, block, 0, s, (const u64 *)ei, c_E, shift, bits, c_hist, eo);
             pt.mark("k_scatter<entries>");
             u64 *t = ei;
             ei = eo, eo = t;
+            shift += bits;
         }
         hipLaunchKernelGGL((k_rle<u64, RLE_IPT_WIDE, RLE_NT>), dim3((uint32_t)(((uint64_t)l.n_tiles * TILE + RLE_NT * RLE_IPT_WIDE - 1) / (RLE_NT * RLE_IPT_WIDE))), dim3(RLE_NT), 0, s, (const u64 *)ei, scal, status, (const uint32_t *)total, first_col, M, max_nz,
                            d_data, d_col_ind, d_row_ind, tasks, l.task_cap, (const uint32_t *)nullptr, 0);

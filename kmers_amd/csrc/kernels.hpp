@@ -32,6 +32,7 @@ struct Knobs {
     int old_pass0 = 0;                    // KMERS_X_OLD_PASS0: the position-ordered pass 0 of rounds 1-2
     unsigned long long x_chunk_pos = 0;   // KMERS_X_CHUNK_POS: positions per device call of the file-level X calls (0: the limit)
     int verbose = 0;                      // KMERS_VERBOSE
+    int wide14 = 0;                       // KMERS_X_WIDE14: K = 14 in three passes of 10 + 9 + 9 bits (measured: no faster)
 };
 const Knobs &knobs();
 int set_knob(const char *name, long long value);   // "reset" re-reads the environment; 0 or -12

@@ -273,3 +273,17 @@ def test_x_fused_emit_equals_the_run_length_path(product, oracle, syn, knob):
             knob("x_path", x_path)
             knob("old_pass0", old0)
             kmtest.assert_x_equal(product.x(files, K), want)
+
+
+def test_x14_in_three_passes_equals_four(product, oracle, syn, knob):
+    """K = 14 has a second pass plan (10 + 9 + 9 bits: 1024-bin pass 0 with the compact staging, two 512-bin passes; knob
+    wide14), measured no faster than four 8-bit passes and therefore not the default: same matrix either way."""
+    files = [syn["iso"], syn["uni"]]
+    want = oracle.x(files, 14)
+    kmtest.assert_x_equal(product.x(files, 14), want)
+    knob("wide14")
+    kmtest.assert_x_equal(product.x(files, 14), want)
+    knob("x_path", 2)          # rounds 1-2: 8-bit digits, position-ordered kernels
+    kmtest.assert_x_equal(product.x(files, 14), want)
+    kmtest.assert_x_equal(product.x(files, 13), oracle.x(files, 13))
+    kmtest.assert_x_equal(product.x(files, 9), oracle.x(files, 9))

@@ -27,7 +27,10 @@ for line in out.splitlines():
         k, v = t.split(":", 1)
         rows[cur][k.strip()] = v.strip()
 names = list(rows)
-dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
+if not names:
+    print(out[-3000:])
+    sys.exit(1)
+dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True, stdin=subprocess.DEVNULL).stdout.split("\n")
 for n, d in zip(names, dem):
     r = rows[n]
     d = re.sub(r"\(.*", "", d).replace("void kk::", "")
