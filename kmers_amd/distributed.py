@@ -77,29 +77,66 @@ def _dist():
     return dist
 
 
-def count_y_sharded(files, K, fastq=False, device=None, count_fn=None):
-    """Every rank returns the full histogram (int32 numpy[4^K]) of `files`, each having counted 1/world of the
-    records.  count_fn(store, K) -> int32 tensor replaces the HIP call in CPU tests only."""
+def _all_reduce_sum(t):
+    """Sum a tensor over the ranks, in place.  The math stays where the tensor is; only the collective goes through the host
+    when the backend cannot take device tensors (gloo: CPU tests, and rehearsals of the multi-rank flow on a one-GPU
+    box -- RCCL refuses two ranks on one device)."""
+    dist = _dist()
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def count_y_sharded(files, K, fastq=False, device=None, reduce_scatter=False):
+    """Every rank returns the full histogram (int32 numpy[4^K]) of `files`, each having counted 1/world of the records:
+    ONE all-reduce(sum) of int32[4^K] over RCCL (the reference's shared-array increment, src/libkmers.cpp:213-216, across
+    GPUs).  reduce_scatter=True (the consumer is the host): every rank reduces and returns only its 1/world slice of the
+    bins, (first_bin, int32 numpy) -- 1/world of the bytes per GPU over xGMI and over PCIe."""
     import torch
     dist = _dist()
     rank, world = dist.get_rank(), dist.get_world_size()
     st = ingest_sharded(files, MODE_Y_FASTQ if fastq else MODE_Y_FASTA)
-    if count_fn is None:
-        counts = st.to_device(device or "cuda").count_y(K)
-    else:
-        counts = count_fn(st, K)
-    dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # RCCL ring over xGMI: 4^K * 4 bytes
-    return counts.cpu().numpy()
+    counts = st.to_device(device or "cuda").count_y(K)
+    if not reduce_scatter:
+        _all_reduce_sum(counts)      # RCCL ring over xGMI: 4^K * 4 bytes
+        return counts.cpu().numpy()
+    M = counts.numel()
+    per = -(-M // world)
+    if counts.is_cuda and dist.get_backend() != "gloo":
+        padded = counts if per * world == M else torch.cat([counts, counts.new_zeros(per * world - M)])
+        mine = torch.empty(per, dtype=counts.dtype, device=counts.device)
+        dist.reduce_scatter_tensor(mine, padded, op=dist.ReduceOp.SUM)
+    else:                            # gloo has no reduce-scatter: the same result from the all-reduce
+        _all_reduce_sum(counts)
+        mine = counts[rank * per:(rank + 1) * per]
+    lo = min(rank * per, M)
+    return lo, mine[:max(0, min(per, M - lo))].cpu().numpy()
 
 
 _SHM_DIR = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
 _shm_serial = itertools.count()
 
 
+def _same_host_or_raise(dist, rank, world):
+    """concat_x_shards maps one set of /dev/shm files on every rank: all ranks must share a host (one node, as
+    BASELINE.json's configurations are).  Every rank learns it and raises alike otherwise."""
+    import socket
+    names = [None] * world
+    dist.all_gather_object(names, socket.gethostname())
+    if len(set(names)) != 1:
+        raise RuntimeError("concat_x_shards needs all ranks on one host (shared-memory output); got hosts %s" % sorted(set(names)))
+
+
 def _rank_prefix(row, dist, rank, world):
     """Exclusive prefix over the ranks of a tensor (Hillis-Steele: ceil(log2 world) rounds of one send and one receive
     of the whole tensor per rank; an all-gather would hold `world` copies -- 16 GB of row pointers at K=14 on 8 GPUs)."""
     import torch
+    if row.is_cuda and dist.get_backend() == "gloo":      # (the collective's hop through the host, see _all_reduce_sum)
+        return _rank_prefix(row.cpu(), dist, rank, world).to(row.device)
     inc = row.clone()
     d = 1
     while d < world:
@@ -118,35 +155,42 @@ def _rank_prefix(row, dist, rank, world):
     return inc - row
 
 
-def concat_x_shards(data, col_ind, row_ind, nnz, n_rows, gloo=False):
+def concat_x_shards(data, col_ind, row_ind, nnz, n_rows):
     """The host-side concatenation of north_star's multi-GPU X: every rank holds the CSR of its column range (torch
-    tensors on its GPU, or on the CPU in the gloo tests; global column numbers; row_ind int64[n_rows + 1]); rank 0
-    returns (data f32, row_ind u64, col_ind u64) of the whole matrix as numpy arrays, the others None.
+    tensors on its GPU, or on the CPU; global column numbers; row_ind int64[n_rows + 1]); rank 0 returns
+    (data f32, row_ind u64, col_ind u64) of the whole matrix as numpy arrays, the others None.
 
     SURVEY.md section 8e's scheme, no pickling and no merge on one rank:
-      * the global row pointer is ONE all-reduce (sum) of the per-rank row pointers (the per-row counts combined);
+      * ONE all-reduce (sum) of the per-row COUNTS, int32[n_rows] (a row holds at most one entry per column: 4 bytes
+        per row, 1 GB at K = 14 -- half of what the int64 row pointers were), whose exclusive scan is the global row
+        pointer;
       * rank g's entries of row r go to  global[r] + (entries of row r on ranks < g), an exclusive prefix over the
-        ranks of the same vector (_rank_prefix);
+        ranks of the same count vector (_rank_prefix);
       * every rank copies its shard to the host over its own PCIe link and writes its rows in place in one POSIX
         shared-memory CSR (kmers_csr_place_rows, all host threads), so the copies and the placement run on all ranks at
-        once."""
+        once.
+    All of the arithmetic runs where the tensors are (on the GPU in production and in the one-GPU rehearsal); the backend
+    only decides how the two collectives travel (_all_reduce_sum).  One node: every rank maps the same /dev/shm files."""
     import torch
     dist = _dist()
     rank, world = dist.get_rank(), dist.get_world_size()
     lib = _lib.handle()
     assert row_ind.dtype == torch.int64 and row_ind.numel() == n_rows + 1
-    on_gpu = row_ind.is_cuda and not gloo
-    comm = (lambda t: t) if on_gpu else (lambda t: t.cpu())      # the tensors the collectives run on
-    row_c = comm(row_ind).contiguous()
-    glob = row_c.clone()
-    dist.all_reduce(glob, op=dist.ReduceOp.SUM)
-    before = _rank_prefix(row_c, dist, rank, world)
+    _same_host_or_raise(dist, rank, world)
+    on_gpu = row_ind.is_cuda
+    row_c = row_ind.contiguous()
+    cnt = (row_c[1:] - row_c[:-1]).to(torch.int32)
+    glob_cnt = _all_reduce_sum(cnt.clone())
+    before = _rank_prefix(cnt, dist, rank, world)
+    glob = torch.zeros(n_rows + 1, dtype=torch.int64, device=row_c.device)
+    torch.cumsum(glob_cnt, 0, dtype=torch.int64, out=glob[1:])
+    del glob_cnt
     total = int(glob[-1].item())
     def all_ok(err):
         """Every rank learns whether any rank failed its local step, so that all of them leave together (a rank that
         raised on its own would leave the others waiting in the next collective)."""
         flag = torch.tensor([0 if err is None else 1], dtype=torch.int32)
-        if on_gpu:
+        if on_gpu and dist.get_backend() != "gloo":
             flag = flag.cuda()
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()):
@@ -170,12 +214,11 @@ def concat_x_shards(data, col_ind, row_ind, nnz, n_rows, gloo=False):
         # where the vectors are (on the GPU with RCCL) and only for the rows this rank has entries in -- a column shard at
         # K = 14 fills a sixth of its 2^28 rows --, so the list of (source start, length, destination) crosses PCIe, not
         # the row vectors (rank 0 also takes the global pointer)
-        cnt = row_c[1:] - row_c[:-1]
         rows = torch.nonzero(cnt).squeeze(1)
         n_list = int(rows.numel())
         src = row_c[:-1][rows]
-        dst = (glob[:-1] + (before[1:] - before[:-1]))[rows]
-        ln = cnt[rows].to(torch.int32)
+        dst = glob[:-1][rows] + before[rows]
+        ln = cnt[rows]
         del before, cnt
         h_data, h_col = to_host(data, nnz), to_host(col_ind, nnz)
         h_src, h_dst, h_len = to_host(src, n_list), to_host(dst, n_list), to_host(ln, n_list)
@@ -215,10 +258,25 @@ def concat_x_shards(data, col_ind, row_ind, nnz, n_rows, gloo=False):
     if base[0] is None:                               # (every rank raises: no collective is left half done)
         raise RuntimeError("concat_x_shards: no room for the whole matrix (%d non-zeros) in %s or %s"
                            % (total, _SHM_DIR, tempfile.gettempdir()))
-    err, out = None, None
+    err, out, maps = None, None, None
     try:
-        o_data, o_col, o_row = (np.memmap(base[0] + ".%d" % i, dtype=dt, mode="r+", shape=(n,))
-                                for i, (n, dt) in enumerate(shapes))
+        maps = [np.memmap(base[0] + ".%d" % i, dtype=dt, mode="r+", shape=(n,)) for i, (n, dt) in enumerate(shapes)]
+    except (OSError, ValueError) as e:
+        err = e
+    # every rank has the files mapped (or has failed): rank 0 unlinks them NOW, so that nothing stays in /dev/shm if a
+    # rank dies from here on; the mappings keep the pages until they go
+    try:
+        dist.barrier()
+    finally:
+        if rank == 0:
+            for i in range(3):
+                try:
+                    os.unlink(base[0] + ".%d" % i)
+                except OSError:
+                    pass
+    all_ok(err)
+    try:
+        o_data, o_col, o_row = maps
         rc = lib.kmers_csr_place_rows(n_list, h_src.ctypes.data, h_len.ctypes.data, h_dst.ctypes.data, h_data.ctypes.data,
                                       h_col.ctypes.data, o_data.ctypes.data, o_col.ctypes.data)
         _lib.check(rc, "kmers_csr_place_rows")
@@ -227,37 +285,20 @@ def concat_x_shards(data, col_ind, row_ind, nnz, n_rows, gloo=False):
             out = (o_data[:total], o_row, o_col[:total])
     except (OSError, ValueError, RuntimeError, MemoryError) as e:
         err = e
-    try:
-        all_ok(err)                                   # (also the barrier: every rank has written its rows)
-    finally:
-        if rank == 0:
-            for i in range(3):
-                try:
-                    os.unlink(base[0] + ".%d" % i)
-                except OSError:
-                    pass
+    all_ok(err)                                       # (also the barrier: every rank has written its rows)
     return out
 
 
-def build_x_sharded(files, K, L=0, concatenate_subseq=False, device=None, build_fn=None):
-    """Rank 0 returns (data, row_ind, col_ind, n_cols) of the whole matrix; other ranks return None.
-    build_fn(store, K) -> (data, row_ind, col_ind) numpy replaces the HIP call in CPU tests only."""
-    import torch
+def build_x_sharded(files, K, L=0, concatenate_subseq=False, device=None):
+    """Rank 0 returns (data, row_ind, col_ind, n_cols) of the whole matrix; other ranks return None."""
     dist = _dist()
-    rank, world = dist.get_rank(), dist.get_world_size()
+    rank = dist.get_rank()
     st = ingest_sharded(files, MODE_X_CAT if concatenate_subseq else MODE_X, L=L)
     M = 4 ** K
-    if build_fn is None:
-        ds = st.to_device(device or "cuda")
-        buf = ds.x_buffers(K, st.n_windows(K))
-        nnz = ds.build_x(buf)
-        res = concat_x_shards(buf["data"], buf["col_ind"], buf["row_ind"], nnz, M,
-                              gloo=dist.get_backend() == "gloo")
-    else:
-        d, r, c = build_fn(st, K)
-        res = concat_x_shards(torch.from_numpy(np.ascontiguousarray(d, np.float32)),
-                              torch.from_numpy(np.ascontiguousarray(c, np.uint64).view(np.int64)),
-                              torch.from_numpy(np.ascontiguousarray(r, np.uint64).view(np.int64)), int(len(d)), M, gloo=True)
+    ds = st.to_device(device or "cuda")
+    buf = ds.x_buffers(K, st.n_windows(K))
+    nnz = ds.build_x(buf)
+    res = concat_x_shards(buf["data"], buf["col_ind"], buf["row_ind"], nnz, M)
     if rank != 0:
         return None
     return np.asarray(res[0]), np.asarray(res[1]), np.asarray(res[2]), st.n_rec_total
@@ -273,11 +314,9 @@ class ShardedModel:
         val, grad_g = terms(xtheta), (ynnz / xtheta) . xnnz_g          per rank, no further exchange for grad_g
 
     (reference kmerexpr/utils.py:76-108 on kmerexpr/multinomial_simplex_model.py:56-62's xnnz / ynnz).  The float32
-    partial products are summed by the collective, so the result depends on the number of ranks in the last bits.
-    make_model(store, K, y) -> an object with n_cols, n_masked, xtheta_into(theta, out), grad_from(xtheta, nograd)
-    replaces the HIP model in CPU tests only."""
+    partial products are summed by the collective, so the result depends on the number of ranks in the last bits."""
 
-    def __init__(self, iso_files, reads_files, K, L=0, fastq=False, device=None, count_fn=None, make_model=None):
+    def __init__(self, iso_files, reads_files, K, L=0, fastq=False, device=None):
         import torch
         dist = _dist()
         rank, world = dist.get_rank(), dist.get_world_size()
@@ -285,24 +324,18 @@ class ShardedModel:
         xs = ingest_sharded(iso_files, MODE_X, L=L)
         ys = ingest_sharded(reads_files, MODE_Y_FASTQ if fastq else MODE_Y_FASTA)
         self.T, self.first_col, self.n_local = xs.n_rec_total, xs.first_rec, xs.n_rec
-        if make_model is None:
-            dev = torch.device(device or "cuda")
-            counts = ys.to_device(dev).count_y(K)
-            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-            dx = xs.to_device(dev)
-            buf = dx.x_buffers(K, xs.n_windows(K))
-            dx.build_x(buf)
-            buf["workspace"] = None
-            from .model import DeviceModel
-            self.model = DeviceModel(buf["data"], buf["col_ind"], buf["row_ind"], max(self.n_local, 1), counts,
-                                     first_col=self.first_col)
-            self._x = buf                      # the model holds its own copy of xnnz; X itself stays for the caller
-            self.device = dev
-        else:
-            counts = count_fn(ys, K)
-            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-            self.model = make_model(xs, K, counts)
-            self.device = torch.device("cpu")
+        dev = torch.device(device or "cuda")
+        counts = ys.to_device(dev).count_y(K)
+        _all_reduce_sum(counts)
+        dx = xs.to_device(dev)
+        buf = dx.x_buffers(K, xs.n_windows(K))
+        dx.build_x(buf)
+        buf["workspace"] = None
+        from . import model as _model
+        self.model = _model.DeviceModel(buf["data"], buf["col_ind"], buf["row_ind"], max(self.n_local, 1), counts,
+                                        first_col=self.first_col)
+        self._x = buf                      # the model holds its own copy of xnnz; X itself stays for the caller
+        self.device = counts.device
         self.N = int(counts.sum(dtype=torch.int64).item())
         self._xtheta = torch.empty(self.model.n_masked, dtype=torch.float32, device=self.device)
         self._theta = torch.zeros(max(self.n_local, 1), dtype=torch.float32, device=self.device)
@@ -318,12 +351,12 @@ class ShardedModel:
         lo, n = self.first_col, self.n_local
         self._theta[:n].copy_(torch.from_numpy(theta[lo:lo + n]))
         self.model.xtheta_into(self._theta, self._xtheta)
-        dist.all_reduce(self._xtheta, op=dist.ReduceOp.SUM)
+        _all_reduce_sum(self._xtheta)
         out = self.model.grad_from(self._xtheta, nograd=nograd)
         if nograd:
             return out
         val, grad_local = out
         self._full.zero_()
         self._full[lo:lo + n].copy_(grad_local[:n])
-        dist.all_reduce(self._full, op=dist.ReduceOp.SUM)     # T floats: assembling the shards, not a reduction of data
+        _all_reduce_sum(self._full)     # T floats: assembling the shards, not a reduction of data
         return val, self._full.cpu().numpy()

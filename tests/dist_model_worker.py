@@ -1,5 +1,5 @@
 """Worker of the sharded-fit tests: one rank of a world_size-N gloo job.
-  cpu  (tests/test_dist_cpu.py): the per-shard engine is the numpy oracle (make_model hook, test infrastructure only);
+  cpu  (tests/test_dist_cpu.py): the per-shard engine is the numpy oracle (patched in by this worker, test infrastructure only);
        what is exercised is the column sharding, the all-reduce of xtheta and the assembly of the gradient.
   gpu  (tests/test_model_gpu.py): the real HIP model on every rank, all ranks on GPU 0 (a one-GPU box; RCCL refuses two
        ranks on one device, so the collective runs over gloo): a rehearsal of the multi-GPU control flow."""
@@ -23,21 +23,15 @@ from oracle import logp_grad as orc  # noqa: E402
 from tests import kmtest  # noqa: E402
 
 
-def _rewrite(store, path):
-    with open(path, "wb") as f:
-        for i, s in enumerate(store.sequences()):
-            f.write(b">r%d\n" % i + s + b"\n")
-
-
 class OracleShard:
-    def __init__(self, oracle, store, K, counts, tmp, rank):
-        p = os.path.join(tmp, f"mx{rank}.fsa")
-        _rewrite(store, p)
-        rc, data, row, col, n_cols = oracle.x([p], K, max_nz=store.n_pos + 16)
-        assert rc == 0 and n_cols == store.n_rec
-        x = csr_matrix((data, col.astype(np.int64), row.astype(np.int64)), shape=(4 ** K, max(n_cols, 1)))
+    """Stand-in for kmers_amd.model.DeviceModel (same constructor and methods) on the numpy oracle: CPU workers only."""
+
+    def __init__(self, data, col_ind, row_ind, n_cols, counts, first_col=0):
+        M = row_ind.numel() - 1
+        nnz = int(row_ind[-1])
+        x = csr_matrix((data.numpy()[:nnz], col_ind.numpy()[:nnz] - first_col, row_ind.numpy()), shape=(M, n_cols))
         self.rows, self.xnnz, self.ynnz = orc.model_setup(x, counts.numpy())
-        self.n_cols, self.n_masked = max(n_cols, 1), self.rows.shape[0]
+        self.n_cols, self.n_masked = n_cols, self.rows.shape[0]
 
     def xtheta_into(self, theta, out):
         out.copy_(torch.from_numpy(self.xnnz.dot(theta.numpy().astype(np.float64)).astype(np.float32)))
@@ -54,19 +48,11 @@ def main():
     iso, reads, K, out = sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
     dist.init_process_group("gloo")
     rank = dist.get_rank()
-    if mode == "cpu":
-        oracle = kmtest.load_oracle()
-        tmp = tempfile.mkdtemp()
-
-        def count_fn(store, K):
-            p = os.path.join(tmp, f"my{rank}.fsa")
-            _rewrite(store, p)
-            rc, y = oracle.y([p], K)
-            assert rc == 0
-            return torch.from_numpy(y.copy())
-
-        model = kd.ShardedModel(iso, reads, K, count_fn=count_fn,
-                                make_model=lambda st, K, counts: OracleShard(oracle, st, K, counts, tmp, rank))
+    if mode == "cpu":       # the engine is swapped HERE, in the test worker: the product's classes have no hooks
+        from kmers_amd import model as _model
+        kmtest.patch_oracle_engine(tempfile.mkdtemp(), f"m{rank}")
+        _model.DeviceModel = OracleShard
+        model = kd.ShardedModel(iso, reads, K, device="cpu")
     else:
         torch.cuda.set_device(0)
         model = kd.ShardedModel(iso, reads, K, device="cuda:0")

@@ -194,3 +194,43 @@ def write_fasta_py_inputs(directory):
             f.write(text)
         made.append(p)
     return made
+
+
+# ---- the oracle as the per-rank engine of the multi-process CPU tests (tests/dist_worker.py, dist_model_worker.py): the
+# workers patch kmers_amd.store.Store.to_device with this, so that the product's sharded flows (ingest shards,
+# collectives, CSR placement) run unchanged on a box without a GPU.  Test infrastructure only.
+
+class OracleDeviceStore:
+    def __init__(self, store, oracle, tmpdir, tag):
+        self.st, self.oracle = store, oracle
+        self.n_pos, self.n_rec, self.first_rec, self.n_rec_total = store.n_pos, store.n_rec, store.first_rec, store.n_rec_total
+        self.path = os.path.join(tmpdir, f"shard_{tag}_{id(store)}.fsa")
+        with open(self.path, "wb") as f:
+            for i, q in enumerate(store.sequences()):
+                f.write(b">r%d\n" % i + q + b"\n")
+
+    def count_y(self, K, counts=None, stream=None, workspace=None):
+        import torch
+        rc, y = self.oracle.y([self.path], K)
+        assert rc == 0
+        return torch.from_numpy(y.copy())
+
+    def x_buffers(self, K, max_nz):
+        return dict(K=K, max_nz=max_nz)
+
+    def build_x(self, buf, stream=None):
+        import torch
+        rc, data, row, col, n_cols = self.oracle.x([self.path], buf["K"], max_nz=self.n_pos + 16)
+        assert rc == 0 and n_cols == self.n_rec
+        buf["data"] = torch.from_numpy(np.ascontiguousarray(data, np.float32))
+        buf["col_ind"] = torch.from_numpy((col + np.uint64(self.first_rec)).view(np.int64).copy())
+        buf["row_ind"] = torch.from_numpy(np.ascontiguousarray(row, np.uint64).view(np.int64).copy())
+        return int(data.shape[0])
+
+
+def patch_oracle_engine(tmpdir, tag):
+    """Make Store.to_device return the oracle-backed stand-in (CPU workers only)."""
+    from kmers_amd import store as _store
+    oracle = load_oracle()
+    _store.Store.to_device = lambda self, device="cuda": OracleDeviceStore(self, oracle, tmpdir, tag)
+    return oracle
