@@ -505,8 +505,126 @@ void pack_piece(const Piece &pc, uint64_t dst, uint32_t *bases, uint32_t *valid)
 // Lines 1, 5, 9, ... (0-based) of the inflated stream, '\n'-terminated ones only, joined with nothing in between.
 // The reference reads through an 8192-byte window and returns an empty sequence as soon as a line does not fit
 // in it, i.e. when any line (terminated or not) is 8192 bytes or longer; so does this.
-bool read_fastq_sequence(const char *path, std::vector<uint8_t> &seq) {
+// The line state machine, fed piece by piece with the inflated stream.
+struct FastqLines {
+    std::vector<uint8_t> &seq;
+    uint64_t line_no = 0;
+    size_t line_len = 0;    // bytes of the current line seen so far
+    size_t committed = 0;   // seq.size() at the start of the current (uncommitted) sequence line
+    bool bad = false;
+    explicit FastqLines(std::vector<uint8_t> &s) : seq(s) {}
+    void feed(const uint8_t *p, size_t n) {
+        const uint8_t *end = p + n;
+        while (!bad && p < end) {
+            const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
+            const uint8_t *e = nl ? nl : end;
+            const size_t m = (size_t)(e - p);
+            if (line_len + m >= 8192) {
+                bad = true;
+                return;
+            }
+            if ((line_no & 3) == 1) seq.insert(seq.end(), p, e);
+            line_len += m;
+            if (!nl) return;
+            if ((line_no & 3) == 1) committed = seq.size();  // line complete
+            ++line_no;
+            line_len = 0;
+            p = nl + 1;
+        }
+    }
+};
+
+// One gzip member inflated from `src` (zlib, gzip wrapper, CRC checked): true iff it ended cleanly; *used = its bytes.
+bool inflate_member(const uint8_t *src, size_t n, std::vector<uint8_t> &out, size_t *used) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 15 + 16) != Z_OK) return false;
+    out.clear();
+    out.resize(std::max<size_t>(1u << 16, std::min<size_t>(n * 4, (size_t)1 << 28)));
+    size_t in_at = 0, out_at = 0;
+    int rc = Z_OK;
+    while (rc != Z_STREAM_END) {
+        if (zs.avail_in == 0) {
+            const size_t take = std::min<size_t>(n - in_at, (size_t)1 << 30);
+            if (take == 0) break;  // the input ran out inside the member
+            zs.next_in = const_cast<Bytef *>(src + in_at);
+            zs.avail_in = (uInt)take;
+            in_at += take;
+        }
+        if (out_at == out.size()) out.resize(out.size() * 2);
+        const size_t room = std::min<size_t>(out.size() - out_at, (size_t)1 << 30);
+        zs.next_out = out.data() + out_at;
+        zs.avail_out = (uInt)room;
+        rc = inflate(&zs, Z_NO_FLUSH);
+        out_at += room - zs.avail_out;
+        if (rc != Z_OK && rc != Z_STREAM_END && !(rc == Z_BUF_ERROR && (zs.avail_in == 0 || zs.avail_out == 0))) break;
+    }
+    const bool ok = rc == Z_STREAM_END;
+    *used = in_at - zs.avail_in;
+    inflateEnd(&zs);
+    out.resize(ok ? out_at : 0);
+    return ok;
+}
+
+// Multi-member gzip (bgzip output, or .gz files laid end to end: what sequencers and `cat` produce) on all host threads.
+// gzip has no index, so members are found by SPECULATION: every offset that looks like a member header (1f 8b 08, reserved
+// flag bits zero) is inflated as if a member started there, one candidate per task; then the chain is followed from offset
+// 0 -- a member's end must be the next member's start -- and only candidates on the chain count (a look-alike inside
+// compressed data fails or is never reached).  Returns false -- and the caller takes the serial gzread path, whose exact
+// behaviour on damaged input is the reference's -- unless the chain covers the file exactly with every member intact.
+bool inflate_members_parallel(const uint8_t *p, size_t n, std::vector<std::vector<uint8_t>> &parts) {
+    std::vector<size_t> cand;
+    for (size_t i = 0; i + 10 <= n;) {
+        const uint8_t *q = (const uint8_t *)memchr(p + i, 0x1f, n - 10 - i + 1);
+        if (!q) break;
+        i = (size_t)(q - p);
+        if (p[i + 1] == 0x8b && p[i + 2] == 8 && (p[i + 3] & 0xe0) == 0) cand.push_back(i);
+        ++i;
+    }
+    if (cand.size() < 2 || cand[0] != 0 || cand.size() > ((size_t)1 << 20)) return false;
+    struct Try {
+        std::vector<uint8_t> out;
+        size_t used = 0;
+        bool ok = false, done = false;
+    };
+    std::vector<Try> tries(cand.size());
+    // candidates are cheap to reject (a look-alike fails within a few bytes), real members cost their size
+    parallel_for(cand.size(), 1, [&](size_t lo, size_t hi) {
+        for (size_t c = lo; c < hi; ++c) {
+            tries[c].ok = inflate_member(p + cand[c], n - cand[c], tries[c].out, &tries[c].used);
+            tries[c].done = true;
+        }
+    });
+    parts.clear();
+    size_t at = 0;
+    while (at < n) {
+        const auto it = std::lower_bound(cand.begin(), cand.end(), at);
+        if (it == cand.end() || *it != at) return false;  // the stream does not go on with a member here
+        Try &t = tries[(size_t)(it - cand.begin())];
+        if (!t.ok || t.used == 0) return false;
+        parts.push_back(std::move(t.out));
+        at += t.used;
+    }
+    return at == n;
+}
+
+bool read_fastq_sequence(const char *path, std::vector<uint8_t> &seq, bool members_in_parallel) {
     seq.clear();
+    if (members_in_parallel) {  // (fewer files than threads: the threads go to the members of one file)
+        FileView fv;
+        std::vector<std::vector<uint8_t>> parts;
+        if (fv.open(path) && fv.n >= 20 && fv.p[0] == 0x1f && fv.p[1] == 0x8b && inflate_members_parallel(fv.p, fv.n, parts)) {
+            FastqLines fl(seq);
+            for (const auto &part : parts) fl.feed(part.data(), part.size());
+            if (fl.bad) {
+                seq.clear();
+                return false;
+            }
+            seq.resize(fl.committed);  // drop an unterminated tail
+            return true;
+        }
+        seq.clear();
+    }
     gzFile in = gzopen(path, "rb");
     if (!in) {
         fprintf(stderr, "Invalid file: %s\n", path);
@@ -514,32 +632,11 @@ bool read_fastq_sequence(const char *path, std::vector<uint8_t> &seq) {
     }
     gzbuffer(in, 1u << 20);
     std::vector<uint8_t> buf(1u << 20);
-    uint64_t line_no = 0;
-    size_t line_len = 0;    // bytes of the current line seen so far
-    size_t committed = 0;   // seq.size() at the start of the current (uncommitted) sequence line
-    bool bad = false;
+    FastqLines fl(seq);
     int got;
-    while (!bad && (got = gzread(in, buf.data(), (unsigned)buf.size())) > 0) {
-        const uint8_t *p = buf.data(), *end = p + got;
-        while (p < end) {
-            const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
-            const uint8_t *e = nl ? nl : end;
-            const size_t n = (size_t)(e - p);
-            if (line_len + n >= 8192) {
-                bad = true;
-                break;
-            }
-            if ((line_no & 3) == 1) seq.insert(seq.end(), p, e);
-            line_len += n;
-            if (!nl) break;
-            // line complete
-            if ((line_no & 3) == 1) committed = seq.size();
-            ++line_no;
-            line_len = 0;
-            p = nl + 1;
-        }
-    }
-    if (got < 0) {
+    while (!fl.bad && (got = gzread(in, buf.data(), (unsigned)buf.size())) > 0) fl.feed(buf.data(), (size_t)got);
+    bool bad = fl.bad;
+    if (!bad && got < 0) {
         int err;
         fprintf(stderr, "%s\n", gzerror(in, &err));
         bad = true;
@@ -552,7 +649,7 @@ bool read_fastq_sequence(const char *path, std::vector<uint8_t> &seq) {
         seq.clear();
         return false;
     }
-    seq.resize(committed);  // drop an unterminated tail
+    seq.resize(fl.committed);  // drop an unterminated tail
     return true;
 }
 
@@ -627,9 +724,15 @@ int ingest(int n_files, const char *fnames[], int mode, int L, int shard, int n_
     RawVec<Piece> pieces;      // in global record order (records without bases have no piece, or one that takes 0)
 
     if (fastq) {
-        parallel_for((size_t)n_files, 1, [&](size_t lo, size_t hi) {
-            for (size_t f = lo; f < hi; ++f) read_fastq_sequence(fnames[f], fq[f]);
-        });
+        // files side by side when there are enough of them to keep the threads busy, else file after file with the
+        // members of each inflated side by side (reference src/libkmers.cpp:240-300 is one serial gzread loop per file)
+        if (n_files >= kmers::host_threads() || kmers::host_threads() == 1) {
+            parallel_for((size_t)n_files, 1, [&](size_t lo, size_t hi) {
+                for (size_t f = lo; f < hi; ++f) read_fastq_sequence(fnames[f], fq[f], false);
+            });
+        } else {
+            for (int f = 0; f < n_files; ++f) read_fastq_sequence(fnames[f], fq[(size_t)f], true);
+        }
         for (int f = 0; f < n_files; ++f) {
             if (!pieces.push(Piece{fq[f].data(), fq[f].data() + fq[f].size(), (uint64_t)f, 0, fq[f].size(), false}) ||
                 !rec_len.push(fq[f].size()))

@@ -253,3 +253,76 @@ except RuntimeError as e:
     r = subprocess.run([sys.executable, "-c", script], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "RAISED" in r.stdout and "no usable HIP device" in r.stderr
+
+
+# ---- multi-member FASTQ.gz on all host threads (reference src/libkmers.cpp:240-300 is one serial
+# gzread loop): members are found by speculation and only the chain from offset 0 counts.
+
+def _fastq_text(rng, n_reads, read_len=100, weird=False):
+    out = bytearray()
+    bases = np.frombuffer(b"ACGT", np.uint8)
+    for i in range(n_reads):
+        seq = bytes(rng.choice(bases, read_len))
+        qual = b"I" * read_len
+        if weird and i % 97 == 0:
+            qual = b"\x1f\x8b\x08\x00" + qual[4:]       # looks like a gzip member header inside the text
+        out += b"@r%d\n%s\n+\n%s\n" % (i, seq, qual)
+    return bytes(out)
+
+
+def _members(text, n, level=6, cut_lines=False):
+    import gzip
+    step = len(text) // n
+    cuts = [0] + [step * i + (37 if cut_lines else 0) for i in range(1, n)] + [len(text)]
+    return b"".join(gzip.compress(text[a:b], compresslevel=level) for a, b in zip(cuts, cuts[1:]))
+
+
+def _reads_of(text):
+    lines = text.split(b"\n")
+    terminated = lines[:-1]                                  # the last piece has no newline behind it
+    return b"".join(terminated[1::4])
+
+
+@pytest.mark.parametrize("level,weird", [(6, False), (0, True), (9, True)])
+def test_multi_member_fastq_gz_equals_serial(tmp_path, monkeypatch, level, weird):
+    """16 members cut in the middle of lines; level 0 keeps the text verbatim in the file, so the planted header
+    look-alikes are candidates that the chain must skip.  One thread (serial gzread) == eight threads (members side by
+    side) == the lines read in python."""
+    rng = np.random.default_rng(11 + level)
+    text = _fastq_text(rng, 4000, weird=weird)
+    p = tmp_path / "m.fastq.gz"
+    p.write_bytes(_members(text, 16, level, cut_lines=True))
+    want = [bytes(c if c in b"ACGT" else ord("N") for c in _reads_of(text))]
+    for threads in ("1", "8"):
+        monkeypatch.setenv("KMER_NUM_THREADS", threads)
+        assert Store(str(p), MODE_Y_FASTQ).sequences() == want, threads
+    # a truncated last member, trailing garbage, an unterminated tail: whatever the serial reader makes of it
+    blob = p.read_bytes()
+    for i, damaged in enumerate((blob[:-9], blob + b"garbage", _members(text[:-40], 5, level))):
+        q = tmp_path / f"d{i}.fastq.gz"
+        q.write_bytes(damaged)
+        monkeypatch.setenv("KMER_NUM_THREADS", "1")
+        serial = Store(str(q), MODE_Y_FASTQ).sequences()
+        monkeypatch.setenv("KMER_NUM_THREADS", "8")
+        assert Store(str(q), MODE_Y_FASTQ).sequences() == serial, i
+
+
+def test_multi_member_fastq_gz_is_faster_on_more_threads(tmp_path, monkeypatch):
+    import time
+    rng = np.random.default_rng(5)
+    text = _fastq_text(rng, 150_000)                        # ~32 MB of text
+    p = tmp_path / "big.fastq.gz"
+    p.write_bytes(_members(text * 4, 16, 6))
+    times = {}
+    for threads in ("1", "8"):
+        monkeypatch.setenv("KMER_NUM_THREADS", threads)
+        best = 1e9
+        for _ in range(2):
+            t0 = time.perf_counter()
+            st = Store(str(p), MODE_Y_FASTQ)
+            best = min(best, time.perf_counter() - t0)
+            n = st.n_bases
+            st.close()
+        times[threads] = best
+        assert n == 4 * 150_000 * 100
+    assert times["8"] < 0.7 * times["1"], times
