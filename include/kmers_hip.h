@@ -125,7 +125,9 @@ int kmers_hip_count_y_ws(const uint32_t *d_bases, size_t bases_words, const uint
 /* kmers_hip_count_y for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc).  No counterpart in the reference.  Same kernels and same result as kmers_hip_count_y_ws, but
  * the scratch of the K >= 9 path is a 32 MiB array that lives inside the library's code object on every GPU it runs on
- * (looked up once per device on the first call there); the store is worked through in chunks that fit it.  The call
+ * (looked up once per device on the first K >= 9 call there: hipGetSymbolAddress, a runtime call that is not
+ * documented as capture-safe -- before capturing, make one call on that device outside the capture; n_pos = 0
+ * suffices and launches nothing); the store is worked through in chunks that fit it.  The call
  * allocates nothing (no hipMalloc / hipFree / events), is asynchronous on `stream`, and takes at most 2^28 positions
  * (KMERS_ERR_TOO_LARGE with a message above that).  All calls on one GPU share the one array: calls that overlap
  * there (two streams, two threads) race -- serialise them. */
@@ -172,6 +174,13 @@ int kmers_hip_debug_knob(const char *name, long long value);
 /* Diagnostic builds only (`python -m kmers_amd.build --stamps`, -DKK_STAMPS): cycle sums of the phases of the two
  * partition kernels (s_memtime, wave 0 of every workgroup).  The product build returns KMERS_ERR_BAD_ARG. */
 int kmers_hip_debug_stamps(unsigned long long *out16, int reset);
+
+/* How many contiguous record ranges the file-level X calls cut an input into when it is above one device call's
+ * limit (cap_pos positions; 0 = the built-in 2^32 - 65536): a record goes to range floor(start * n / n_pos), so a
+ * range holds at most ceil(n_pos / n) + longest_rec_pos - 1 positions and n is chosen to keep that under the cap.
+ * 0 when one record alone is above the cap or more than 4096 ranges would be needed (the calls then return
+ * KMERS_ERR_TOO_LARGE).  Pure host arithmetic; no counterpart in the reference (it has no size limit of this kind). */
+uint64_t kmers_x_range_count(uint64_t n_pos, uint64_t n_rec_total, uint64_t longest_rec_pos, uint64_t cap_pos);
 
 /* ---- host-side merge of per-shard CSRs (multi-GPU X) --------------------------- */
 

@@ -125,6 +125,7 @@ def handle():
     lib.kmers_hip_model_read.restype, lib.kmers_hip_model_read.argtypes = C.c_int, [vp, C.c_int, vp]
     lib.kmers_hip_model_logp_grad.restype = C.c_int
     lib.kmers_hip_model_logp_grad.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_double), vp, vp]
+    lib.kmers_x_range_count.restype, lib.kmers_x_range_count.argtypes = C.c_uint64, [C.c_uint64] * 4
     lib.kmers_last_call_stages.restype, lib.kmers_last_call_stages.argtypes = C.c_int, [C.c_char_p, C.c_size_t]
     lib.kmers_hip_debug_knob.restype, lib.kmers_hip_debug_knob.argtypes = C.c_int, [C.c_char_p, C.c_longlong]
     lib.kmers_hip_profile_enable.restype, lib.kmers_hip_profile_enable.argtypes = None, [C.c_int]

@@ -27,6 +27,7 @@
 //   * bytes >= 0x80 are refused (KMERS_ERR_BAD_ARG): python would decode them (or raise), one character per sequence.
 #include "kmers_hip.h"
 #include "store.hpp"
+#include "kernels.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -699,10 +700,7 @@ int ingest(int n_files, const char *fnames[], int mode, int L, int shard, int n_
     struct Lap {  // KMERS_VERBOSE=2: stage times on stderr
         bool on;
         std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-        Lap() {
-            const char *e = getenv("KMERS_VERBOSE");
-            on = e && atoi(e) >= 2;
-        }
+        Lap() : on(kk::knobs().verbose >= 2) {}
         void operator()(const char *what) {
             if (!on) return;
             const auto t1 = std::chrono::steady_clock::now();
@@ -764,7 +762,7 @@ int ingest(int n_files, const char *fnames[], int mode, int L, int shard, int n_
                 }
                 return KMERS_ERR_OPEN;  // reference src/libkmers.cpp:356-357, 440-441
             }
-            if (getenv("KMERS_VERBOSE")) printf("processing %s\n", fnames[f]);
+            if (kk::knobs().verbose) printf("processing %s\n", fnames[f]);
             // this shard's bytes of the file: headers inside [lo, hi) are its records
             const uint64_t fbase = file_base[f];
             const size_t lo = (size_t)(want_lo > fbase ? want_lo - fbase : 0);

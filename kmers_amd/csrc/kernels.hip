@@ -3353,6 +3353,8 @@ static WidePlan wide_plan(int K, bool classic) {
 }
 static int wide_max_bits(int K) { return K == 14 ? 10 : ((K == 9 || K == 13) ? 9 : 8); }  // (whatever the knobs say)
 
+static bool x_tables_fit(uint64_t n_rec, int K) { return K >= 5 && K <= 8 && n_rec <= DD_MAX_REC; }
+
 struct XLayout {
     uint32_t n_tiles;
     uint32_t dd_rows;        // histogram rows of the small-K path: its tiles + one per workgroup + the all-zero last row
@@ -3368,7 +3370,10 @@ static XLayout x_layout(uint64_t n_pos, uint64_t n_rec, int K) {
     XLayout l;
     const uint64_t emax = n_pos ? n_pos : 1;
     l.n_tiles = (uint32_t)((emax + TILE - 1) / TILE);
-    l.dd_rows = (uint32_t)((emax + DD_C - 1) / DD_C) + DD_GRID + 2;
+    // the small-K table path's buffers exist only where build_x can select it (K and n_rec decide; never a knob: the
+    // layout a caller sized its workspace by must not move under it)
+    const bool tables_fit = x_tables_fit(n_rec, K);
+    l.dd_rows = tables_fit ? (uint32_t)((emax + DD_C - 1) / DD_C) + DD_GRID + 2 : 0;
     // rows of the tile histogram: the partition's tiles (+ 1), the fused emit's region-aligned tiles (at most 256 more, + the
     // all-zero rows behind them), the small-K table path's
     uint32_t rows = l.n_tiles + RADIX + 2;
@@ -3376,7 +3381,7 @@ static XLayout x_layout(uint64_t n_pos, uint64_t n_rec, int K) {
     const uint64_t max_bins = 1ull << wide_max_bits(K);
     l.hist_len = max_bins * rows;
     l.scan_blocks = cscan_chunks(rows);
-    l.esc_cap = (uint32_t)(emax < (1u << 22) ? emax : (1u << 22));
+    l.esc_cap = tables_fit ? (uint32_t)(emax < (1u << 22) ? emax : (1u << 22)) : 0;
     const uint64_t M = 1ull << (2 * K);
     // long gaps: each holds > FILL_INLINE rows and follows a row head, plus the splits of very long ones
     uint64_t cap = (M + 1) / (FILL_INLINE + 1) + 2;
@@ -3400,9 +3405,9 @@ static XLayout x_layout(uint64_t n_pos, uint64_t n_rec, int K) {
     l.off_scalars = take(64);
     l.off_regions = take(3 * (RADIX + 1) * 4);  // regions of two passes, tile starts of the fused emit
     l.off_tasks = take((size_t)l.task_cap * sizeof(FillTask));
-    l.off_wgrec = take((DD_GRID + 1) * 4);
+    l.off_wgrec = take(tables_fit ? (DD_GRID + 1) * 4 : 0);
     l.off_esc = take((size_t)l.esc_cap * sizeof(DDEscape));
-    l.off_rowcount = take((size_t)65536 * 4);
+    l.off_rowcount = take(tables_fit ? (size_t)65536 * 4 : 0);
     l.bytes = o;
     return l;
 }
@@ -3776,7 +3781,7 @@ int build_x(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
     const Knobs kn = knobs();
     {
         const bool want_tables = kn.x_path == 1 && !kn.force_wide;
-        const bool fits = K >= 5 && K <= 8 && n_rec <= DD_MAX_REC;
+        const bool fits = x_tables_fit(n_rec, K);
         if (fits && want_tables) {
             const int rc = build_x_tables(l, d_bases, bases_words, d_valid, valid_words, d_rec_start, n_pos, n_rec, first_col, K,
                                           d_data, d_col_ind, d_row_ind, max_nz, ws, nnz_out, s, pt);

@@ -355,13 +355,13 @@ int build_files(int n_files, const char *fnames[], int K, int L, int mode, float
             *n_cols = (int)n_rec_total;
             return KMERS_OK;
         }
-        n_pos = std::max<uint64_t>(n_pos, 1);
         // more positions than one device call indexes: contiguous record ranges (the ingest's shards, balanced by
         // positions), one matrix each, interleaved row by row at the end (columns ascend from range to range)
-        const uint64_t by_pos = (n_pos + chunk_pos - 1) / chunk_pos, by_rec = n_rec_total / X_MAX_REC + 1;
-        const uint64_t want = std::max(by_pos, by_rec);
-        if (want > 4096) return KMERS_ERR_TOO_LARGE;
-        n_ranges = want;
+        const uint64_t *rs = kmers_store_rec_start(g.s);
+        uint64_t longest = 0;
+        for (uint64_t r = 0, n = kmers_store_n_rec(g.s); r < n; ++r) longest = std::max(longest, rs[r + 1] - rs[r]);
+        n_ranges = kmers_x_range_count(n_pos, n_rec_total, longest, chunk_pos);
+        if (n_ranges == 0) return KMERS_ERR_TOO_LARGE;
     }
     const int n_parts = (int)n_ranges;
     std::vector<HostCsr> parts((size_t)n_parts);
@@ -420,6 +420,19 @@ int report(int rc, const char *call) {
 }  // namespace
 
 extern "C" {
+
+// A record belongs to range floor(start * n_ranges / n_pos) (ingest.cpp), so a range holds at most
+// ceil(n_pos / n_ranges) + longest - 1 positions: the count leaves that much room under the cap.
+uint64_t kmers_x_range_count(uint64_t n_pos, uint64_t n_rec_total, uint64_t longest_rec_pos, uint64_t cap_pos) {
+    if (cap_pos == 0 || cap_pos > X_MAX_POS) cap_pos = X_MAX_POS;
+    if (longest_rec_pos > cap_pos) return 0;
+    uint64_t want = n_rec_total / X_MAX_REC + 1;
+    if (n_pos > cap_pos) {
+        const uint64_t room = cap_pos - longest_rec_pos + 1;   // >= 1
+        want = std::max(want, (n_pos + room - 1) / room);
+    }
+    return want > 4096 ? 0 : want;
+}
 
 // ---- the reference's six symbols ----------------------------------------------------------------------
 
@@ -518,7 +531,9 @@ int kmers_hip_count_y_static(const uint32_t *d_bases, size_t bases_words, const 
     }
     void *ws = nullptr;
     size_t ws_bytes = 0;
-    if (K >= 9 && n_pos)  // K <= 8 counts in LDS and needs no scratch at all
+    // K <= 8 counts in LDS and needs no scratch at all.  The lookup (hipGetSymbolAddress, first call on a device only) is
+    // made for an empty input too: that is the warm-up call of a caller about to capture a graph.
+    if (K >= 9)
         if (int rc = kk::static_scratch(&ws, &ws_bytes)) return rc;
     // the same kernels as kmers_hip_count_y_ws, in chunks that fit the static array; no hipMalloc, no events
     return kk::count_y(d_bases, bases_words, d_valid, valid_words, n_pos, K, d_counts, ws, ws_bytes, (hipStream_t)stream,

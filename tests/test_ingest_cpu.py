@@ -74,6 +74,35 @@ def test_store_shards_partition_records(n_shards):
     assert max(sizes) - min(sizes) <= max(len(s) for s in whole) + 1   # balanced by positions
 
 
+def test_x_range_count_leaves_room_for_the_longest_record(tmp_path):
+    """kmers_x_range_count (the chunked route of the file-level X calls, libkmers.cpp build_files): with the count it
+    returns, no range of the real ingest is above the cap -- on record lengths chosen to overshoot a plain
+    ceil(n_pos / cap): the long records sit right where the even split would cut."""
+    from kmers_amd import _lib
+    lib = _lib.handle()
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        lens = rng.integers(20, 400, size=300)
+        lens[rng.integers(0, 300, size=4)] = rng.integers(3000, 6000, size=4)
+        p = str(tmp_path / f"t{trial}.fsa")
+        with open(p, "w") as f:
+            for i, n in enumerate(lens):
+                f.write(f">r{i}\n" + "".join(rng.choice(list("ACGT"), size=int(n))) + "\n")
+        whole = Store([p], MODE_X)
+        n_pos, longest = whole.n_pos, int(np.diff(whole.rec_start.astype(np.int64)).max())
+        for cap in (longest, longest + 1, longest + 50, 2 * longest, n_pos // 3, n_pos - 1):
+            n = lib.kmers_x_range_count(n_pos, whole.n_rec, longest, cap)
+            if n == 0:
+                assert (n_pos + (cap - longest)) // (cap - longest + 1) > 4096
+                continue
+            sizes = [Store([p], MODE_X, shard=s, n_shards=n).n_pos for s in range(n)]
+            assert sum(sizes) == n_pos and max(sizes) <= cap, (trial, cap, n, max(sizes))
+        assert lib.kmers_x_range_count(n_pos, whole.n_rec, longest, n_pos) == 1
+        assert lib.kmers_x_range_count(n_pos, whole.n_rec, longest, longest - 1) == 0       # one record above the cap
+    assert lib.kmers_x_range_count(10, 2 ** 32, 5, 0) == 3                                  # by records: 2^31 - 1 a call
+    assert lib.kmers_x_range_count(2 ** 34, 1000, 2 ** 20, 0) == 5                          # the built-in cap
+
+
 @pytest.mark.parametrize("n_shards", [2, 3, 7, 64])
 def test_byte_range_shards_are_the_whole_in_order(tmp_path, n_shards):
     """kmers_store_ingest_bytes: every rank parses only its byte range; the shards in order are the whole record list
