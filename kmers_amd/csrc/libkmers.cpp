@@ -364,13 +364,16 @@ int build_files(int n_files, const char *fnames[], int K, int L, int mode, float
         if (n_ranges == 0) return KMERS_ERR_TOO_LARGE;
     }
     const int n_parts = (int)n_ranges;
-    std::vector<HostCsr> parts((size_t)n_parts);
+    std::vector<HostCsr> parts;
+    parts.reserve((size_t)n_parts);
     uint64_t total = 0;
     for (int p = 0; p < n_parts; ++p) {
         StoreGuard g;
         if (int rc = kmers_store_ingest(n_files, fnames, mode, L, p, n_parts, &g.s)) return rc;
+        if (kmers_store_n_rec(g.s) == 0) continue;  // (the room left for the longest record makes some ranges empty)
         const uint64_t windows = kmers_store_n_windows(g.s, K);
-        HostCsr &h = parts[(size_t)p];
+        parts.emplace_back();
+        HostCsr &h = parts.back();
         h.data = (float *)malloc(std::max<uint64_t>(windows, 1) * 4);
         h.col = (uint64_t *)malloc(std::max<uint64_t>(windows, 1) * 8);
         h.row = (uint64_t *)malloc((M + 1) * 8);
@@ -388,7 +391,7 @@ int build_files(int n_files, const char *fnames[], int K, int L, int mode, float
     std::vector<const float *> pd;
     std::vector<const uint64_t *> pr, pc;
     for (const HostCsr &h : parts) pd.push_back(h.data), pr.push_back(h.row), pc.push_back(h.col);
-    if (int rc = kmers_csr_merge(n_parts, M, pd.data(), pr.data(), pc.data(), data, row_ind, col_ind)) return rc;
+    if (int rc = kmers_csr_merge((int)parts.size(), M, pd.data(), pr.data(), pc.data(), data, row_ind, col_ind)) return rc;
     clk.lap("interleave of the ranges");
     return KMERS_OK;
 }

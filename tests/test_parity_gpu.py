@@ -75,10 +75,11 @@ def test_x_first_and_last_row_in_one_round(product, oracle, tmp_path, K):
 def test_x_in_record_ranges_above_the_per_call_limit(product, oracle, syn, K, L, cat, knob):
     """An input of more positions than one device call indexes (2^32 - 65536) is built in contiguous record ranges that
     are interleaved row by row on the host.  The x_chunk_pos knob lowers the limit so that the route runs here: 4 M
-    positions in ranges of at most ~300,000 (14 of them), one file per column in the cat mode (2 ranges)."""
-    files = [syn["iso"], syn["uni"]]
+    positions in ranges of at most 300,000 (the count leaves room for the longest record: kmers_x_range_count); in the
+    cat mode one file is one column, 1 + 3 + 1 M positions under a limit of 3.3 M (17 ranges, 14 of them empty)."""
+    files = [syn["uni"], syn["iso"], syn["uni"]] if cat else [syn["iso"], syn["uni"]]
     want = oracle.x(files, K, L, cat)
-    knob("x_chunk_pos", 2000000 if cat else 300000)
+    knob("x_chunk_pos", 3300000 if cat else 300000)
     kmtest.assert_x_equal(product.x(files, K, L, cat), want)
     nnz = want[1].shape[0]
     assert product.x(files, K, L, cat, max_nz=nnz)[0] == 0
