@@ -436,7 +436,10 @@ __global__ __launch_bounds__(YL_NT) void k_count_y_lds(BasesArgs a, int32_t *cou
 #define HB_BLOCKS 8192
 #endif
 #ifndef YS16_BLOCKS
-#define YS16_BLOCKS 32768
+#define YS16_BLOCKS 65536
+#endif
+#ifndef YS16_NT
+#define YS16_NT 1024
 #endif
 #ifndef YS32_BLOCKS
 #define YS32_BLOCKS 256
@@ -557,117 +560,135 @@ __device__ __forceinline__ WordWindows yword_fetch(const BasesArgs &a, uint32_t 
 
 template <int BNT>
 __global__ __launch_bounds__(BNT) void k_hist_words_y(BasesArgs a, uint32_t *tilehist, uint64_t n_words8, uint32_t n_tiles) {
-    constexpr int BNW = BNT / 64;
-    __shared__ uint32_t h[2][BNW][RADIX];
-    const uint32_t tid = threadIdx.x, w = tid >> 6;
+    // ONE table per tile for all 16 waves (two, used in turn: one is zeroed while the other is filled): LDS atomics of
+    // different waves never meet inside one LDS instruction, so per-wave copies bought nothing and cost a 16-way sum by
+    // a quarter of the threads between two barriers on every tile.
+    __shared__ uint32_t h[2][RADIX];
+    const uint32_t tid = threadIdx.x;
     const uint32_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
     const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
     if (t0 >= t1) return;
     WordWindows nx = yword_fetch<BNT>(a, t0, n_words8);
-    for (uint32_t i = tid; i < BNW * RADIX; i += BNT) (&h[0][0][0])[i] = 0;
+    const uint32_t dshift = 32u - 2u * (uint32_t)a.K + (uint32_t)a.low_bits;  // digit = (id >> low_bits) & 255, id = top 2K bits
+    if (tid < 2 * RADIX) (&h[0][0])[tid] = 0;
     lds_sync();
     for (uint32_t tile = t0; tile < t1; ++tile) {
-        uint32_t(*const hc)[RADIX] = h[(tile - t0) & 1u];
-        uint32_t(*const hn)[RADIX] = h[((tile - t0) & 1u) ^ 1u];
+        uint32_t *const hc = h[(tile - t0) & 1u];
+        uint32_t *const hn = h[((tile - t0) & 1u) ^ 1u];
         const WordWindows x = nx;
         if (tile + 1 < t1) nx = yword_fetch<BNT>(a, tile + 1, n_words8);
-        uint32_t run_d = NONE, run_len = 0;  // equal consecutive digits (poly-A) are added once
+        // One predicated LDS add per window and nothing else: the run-merging loop this replaces (equal consecutive
+        // digits added once) cost ~8 VALU + 9 SALU + 3 branches per window for the sake of poly-A.  A word whose 16
+        // digits are all equal (24 equal bases from its first position on, every window valid) still adds once.
+        const uint32_t okm = (runs_of(x.v, a.K) & 0xFFFFu);
+        const bool mono = okm == 0xFFFFu && __builtin_amdgcn_alignbit(x.b0, x.b1, 30u) == x.b0 && ((x.b0 ^ x.b1) >> 16) == 0u;
+        if (mono) {
+            atomicAdd(&hc[(x.b0 >> dshift) & 255u], 16u);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            uint32_t key;
-            const bool ok = word_window(x, j, a.K, key);
-            const uint32_t d = ok ? ((key >> a.low_bits) & 255u) : NONE;
-            if (d == run_d) {
-                ++run_len;
-            } else {
-                if (run_d != NONE) atomicAdd(&hc[w][run_d], run_len);
-                run_d = d;
-                run_len = 1;
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t top = j ? __builtin_amdgcn_alignbit(x.b0, x.b1, 32u - 2u * (uint32_t)j) : x.b0;
+                if ((okm >> j) & 1u) atomicAdd(&hc[(top >> dshift) & 255u], 1u);
             }
         }
-        if (run_d != NONE) atomicAdd(&hc[w][run_d], run_len);
-        for (uint32_t i = tid; i < BNW * RADIX; i += BNT) (&hn[0][0])[i] = 0;  // the other table, for the next tile
+        if (tid < RADIX) hn[tid] = 0;  // the other table, for the next tile (its readers passed the barrier below)
         lds_sync();
-        if (tid < RADIX) {
-            uint32_t s = 0;
-#pragma unroll
-            for (int i = 0; i < BNW; ++i) s += hc[i][tid];
-            tilehist[(uint64_t)tile * RADIX + tid] = s;
-        }
-        lds_sync();  // the next tile zeroes hc right after its atomics: the readers above must be done first
+        if (tid < RADIX) tilehist[(uint64_t)tile * RADIX + tid] = hc[tid];
+        // no second barrier: hc is zeroed again only after the NEXT tile's barrier, which these reads precede
     }
 }
 
 // y for K >= 9, pass 0 partition: sort key = id >> low_bits, payload = the low bits, no records.  K <= 12: 2-byte
 // entries (the payload; the sort key is the region); K >= 13: 4-byte entries ((sort key >> 8) << 24 | low bits).
 // Order-free: a histogram follows, not a run-length reduce, so the windows come from registers (one packed word per
-// thread) and the rank inside a (digit, tile) is what ONE returning LDS atomic on the tile's digit counter hands out.
+// thread) and the place of an entry inside its (digit, tile) group is what ONE returning LDS atomic hands out.
+// Round 3: the tile's digit counts are not counted again here -- they are the difference of two rows of the scanned
+// tile histogram (row t + 1 minus row t; the region table closes the last tile), so ONE wave turns them into the
+// digit starts of tile t + 1 while tile t is written out, the atomic returns the entry's final slot in the staging
+// array and the entry is stored there at once: no rank registers, no second decode, two barriers per tile instead
+// of six (2.28 -> see DESIGN.md section 4 per 2^31 positions with 2-byte entries).
 // 1024-thread workgroups on tiles of 16,384 positions: the write-out is store-bound and its runs are twice as long as
 // with 8192-position tiles -- 2.17 -> 1.79 ms with 4-byte entries (round 1) and 3.07 -> 2.60 ms per 2^31 positions
 // with 2-byte entries (round 2: 64-byte runs wrote every 128-byte line in two halves, 2.0x WRITE_SIZE in the PMC pass).
-template <class ET, int BNT>
-__global__ __launch_bounds__(BNT) void k_yscatter(BasesArgs a, const uint32_t *tilebase, uint64_t n_words8, uint32_t n_tiles, ET *out) {
-    constexpr int BNW = BNT / 64, BTILE = BNT * 16;
+template <class ET, int BNT, int WPT>
+__global__ __launch_bounds__(BNT) void k_yscatter(BasesArgs a, const uint32_t *tilebase, const uint32_t *regions, uint64_t n_words8,
+                                                  uint32_t n_tiles, ET *out) {
+    constexpr int BNW = BNT / 64, BTILE = BNT * WPT * 16;  // WPT packed words per thread
     __shared__ __attribute__((aligned(16))) ET sent[BTILE];
     __shared__ uint8_t saux[BTILE];
-    __shared__ uint32_t cnt[RADIX], gadj[RADIX], swave[BNW];
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[2][RADIX], gadj[2][RADIX];
+    __shared__ uint32_t s_count[2];
     const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
     const uint32_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
     const uint32_t t0 = blockIdx.x * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
     if (t0 >= t1) return;
     const uint32_t low_mask = (1u << a.low_bits) - 1u;
-    WordWindows nx = yword_fetch<BNT>(a, t0, n_words8);
-    uint32_t gb = (tid < RADIX) ? tilebase[(uint64_t)t0 * RADIX + tid] : 0u;
+    const uint32_t dshift = 32u - 2u * (uint32_t)a.K + (uint32_t)a.low_bits, ksh = 32u - 2u * (uint32_t)a.K;
+    auto fetch = [&](WordWindows *dst, uint32_t tile) {
+#pragma unroll
+        for (int wi = 0; wi < WPT; ++wi) {
+            const uint64_t lw = (uint64_t)tile * (BNT * WPT) + (uint32_t)wi * BNT + tid;  // word inside the chunk
+            dst[wi] = (lw < n_words8) ? word_fetch(a, a.tile0 * NT + lw) : WordWindows{0u, 0u, 0u};
+        }
+    };
+    WordWindows nx[WPT];
+    fetch(nx, t0);
+    // the scan wave (the last one) keeps two rows of the scanned histogram, digits 4 lane .. 4 lane + 3: row_lo = the
+    // bases of the tile it sets up next, row_hi = the row after it
+    const bool scan_wave = w == BNW - 1;
+    auto load_row = [&](uint32_t t) -> uint4 {  // t <= n_tiles
+        if (t < n_tiles) return reinterpret_cast<const uint4 *>(tilebase + (uint64_t)t * RADIX)[lane];
+        return make_uint4(regions[4 * lane + 1], regions[4 * lane + 2], regions[4 * lane + 3], regions[4 * lane + 4]);
+    };
+    uint4 row_lo = make_uint4(0, 0, 0, 0), row_hi = row_lo;
+    auto setup = [&](uint32_t buf) {  // digit starts of the tile whose rows are row_lo / row_hi
+        const uint32_t c0 = row_hi.x - row_lo.x, c1 = row_hi.y - row_lo.y, c2 = row_hi.z - row_lo.z, c3 = row_hi.w - row_lo.w;
+        const uint32_t sum = c0 + c1 + c2 + c3, inc = wave_incl_scan(sum), s0 = inc - sum, s1 = s0 + c0, s2 = s1 + c1, s3 = s2 + c2;
+        reinterpret_cast<uint4 *>(cnt[buf])[lane] = make_uint4(s0, s1, s2, s3);
+        reinterpret_cast<uint4 *>(gadj[buf])[lane] = make_uint4(row_lo.x - s0, row_lo.y - s1, row_lo.z - s2, row_lo.w - s3);
+        if (lane == 63u) s_count[buf] = inc;
+    };
+    if (scan_wave) {
+        row_lo = load_row(t0);
+        row_hi = load_row(t0 + 1);
+        setup(0);
+        row_lo = row_hi;
+    }
+    lds_sync();
     for (uint32_t tile = t0; tile < t1; ++tile) {
-        if (tid < RADIX) cnt[tid] = 0;
-        lds_sync();
-        const WordWindows x = nx;
-        if (tile + 1 < t1) nx = yword_fetch<BNT>(a, tile + 1, n_words8);
-        uint32_t rank[16];  // bits 0..15 the rank inside the digit, bits 16..23 the digit; NONE = no k-mer
+        const uint32_t buf = (tile - t0) & 1u;
+        WordWindows xs[WPT];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            uint32_t key;
-            rank[j] = NONE;
-            if (word_window(x, j, a.K, key)) {
-                const uint32_t d = (key >> a.low_bits) & 255u;
-                rank[j] = atomicAdd(&cnt[d], 1u) | (d << 16);
+        for (int wi = 0; wi < WPT; ++wi) xs[wi] = nx[wi];
+        if (tile + 1 < t1) {
+            fetch(nx, tile + 1);
+            if (scan_wave) row_hi = load_row(tile + 2);
+        }
+#pragma unroll
+        for (int wi = 0; wi < WPT; ++wi) {
+            const WordWindows x = xs[wi];
+            const uint32_t okm = runs_of(x.v, a.K) & 0xFFFFu;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if ((okm >> j) & 1u) {
+                    const uint32_t top = j ? __builtin_amdgcn_alignbit(x.b0, x.b1, 32u - 2u * (uint32_t)j) : x.b0;
+                    const uint32_t d = (top >> dshift) & 255u, key = top >> ksh;
+                    const uint32_t slot = atomicAdd(&cnt[buf][d], 1u);
+                    if constexpr (sizeof(ET) == 2)
+                        sent[slot] = (ET)(key & low_mask);
+                    else
+                        sent[slot] = (ET)((((key >> a.low_bits) >> 8) << 24) | (key & low_mask));
+                    saux[slot] = (uint8_t)d;
+                }
             }
         }
         lds_sync();
-        // exclusive scan of the 256 digit counts (waves 0..3 hold them), tile total
-        const uint32_t dtot = (tid < RADIX) ? cnt[tid] : 0u, inc = wave_incl_scan(dtot);
-        if (lane == 63) swave[w] = inc;
-        lds_sync();
-        uint32_t wbase = 0, tile_count = 0;
-#pragma unroll
-        for (int i = 0; i < RADIX / 64; ++i) {
-            const uint32_t t = swave[i];
-            if ((uint32_t)i < w) wbase += t;
-            tile_count += t;
+        if (scan_wave && tile + 1 < t1) {  // the next tile's digit starts, while this one leaves
+            setup(buf ^ 1u);
+            row_lo = row_hi;
         }
-        if (tid < RADIX) {
-            const uint32_t dstart = wbase + inc - dtot;
-            cnt[tid] = dstart;
-            gadj[tid] = gb - dstart;
-            if (tile + 1 < t1) gb = tilebase[(uint64_t)(tile + 1) * RADIX + tid];
-        }
-        lds_sync();
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (rank[j] != NONE) {
-                uint32_t key;
-                (void)word_window(x, j, a.K, key);
-                const uint32_t d = (rank[j] >> 16) & 255u, sk = key >> a.low_bits;
-                const uint32_t slot = cnt[d] + (rank[j] & 0xFFFFu);
-                if constexpr (sizeof(ET) == 2)
-                    sent[slot] = (ET)(key & low_mask);
-                else
-                    sent[slot] = (ET)(((sk >> 8) << 24) | (key & low_mask));
-                saux[slot] = (uint8_t)d;
-            }
-        }
-        lds_sync();
-        for (uint32_t i = tid; i < tile_count; i += BNT) out[gadj[saux[i]] + i] = sent[i];
+        const uint32_t tile_count = s_count[buf];
+        for (uint32_t i = tid; i < tile_count; i += BNT) out[gadj[buf][saux[i]] + i] = sent[i];
         lds_sync();
     }
 }
@@ -1333,7 +1354,10 @@ __global__ void k_bucket_bounds(const uint32_t *ent, const uint32_t *regions, ui
     bounds[k] = lo;
 }
 
-constexpr int YS_NT = 1024, YS_UNROLL = 4;
+#ifndef YS_UNROLL_N
+#define YS_UNROLL_N 4
+#endif
+constexpr int YS_NT = 1024, YS_UNROLL = YS_UNROLL_N;
 constexpr uint32_t YS_OVF_CHUNK = 1u << 18;  // entries per workgroup pass in the overflow kernel
 
 // What a slice's bins are: everything needed to turn an entry into a bin of the slice's LDS table.
@@ -1359,9 +1383,13 @@ __device__ __forceinline__ YSlice ys_slice(uint32_t slice, int two_pass, int low
 
 // Count entries [begin, end) into h.  All YS_NT threads call it with the same arguments.
 // ET = uint32_t: (sort-key byte << 24 | low bits); ET = uint16_t (one pass, K <= 12): the low bits alone.
-// A thread adds a run of equal consecutive entries (poly-A: 0.7 % of the bench's windows are one k-mer, and 64
-// same-address LDS atomics serialise) once, with its length -- entries of one 16-byte load are consecutive in the
-// partitioned array, which keeps position order inside a (digit, tile) group closely enough for runs to survive.
+// A lane whose 16-byte load holds no two equal neighbours (nearly all of them) makes one predicated LDS add per entry.
+// A lane that meets an equal pair takes that value as its HOT entry and from then on counts its occurrences in a
+// register (added to the table once, at the end or when a later load with a pair no longer holds it).  Why: 0.7 % of the
+// bench's windows are one k-mer (poly-A), they all sit in one slice, and 64 same-address LDS atomics serialise (29 ns
+// per wave instruction): with per-thread merging of adjacent equal entries only (rounds 1-2; in the partitioned array a
+// (digit, tile) group mixes poly-A with other AAAA... k-mers, so the runs are 2-3 long) the poly-A slice's workgroup
+// alone set the duration of the launch -- 1.75 ms per 2^31 positions whatever else was changed in this loop.
 template <uint32_t NB, class ET>
 __device__ __forceinline__ void ys_count_range(uint32_t *h, const ET *ent, uint32_t begin, uint32_t end, const YSlice &y) {
     const uint32_t tid = threadIdx.x;
@@ -1382,38 +1410,70 @@ __device__ __forceinline__ void ys_count_range(uint32_t *h, const ET *ent, uint3
         if (a1 + tid < end) add1(bin_of(ent[a1 + tid]));
         const uint4 *ent4 = reinterpret_cast<const uint4 *>(ent);
         const uint32_t q1 = a1 / PER;
-        for (uint32_t qb = a0 / PER; qb < q1; qb += YS_NT * YS_UNROLL) {
-            uint4 v[YS_UNROLL];
+        // the loads of batch i + 1 are issued before batch i is counted: one workgroup per CU (the table fills the LDS) has
+        // only 16 waves to hide the memory latency with, and without this every wave alternated between waiting and
+        // counting (a slice's workgroup streamed its 15-18 MB at ~10 GB/s)
+        uint4 v[YS_UNROLL], nx[YS_UNROLL];
+        uint32_t hot_v = NONE, hot_n = 0;  // this lane's hot entry value and its occurrences not yet added (see below)
+        auto fetch = [&](uint4 *dst, uint32_t qb) {
 #pragma unroll
             for (int u = 0; u < YS_UNROLL; ++u) {
                 const uint32_t q = qb + u * YS_NT + tid;
-                v[u] = (q < q1) ? ent4[q] : make_uint4(0, 0, 0, 0);
+                dst[u] = (q < q1) ? ent4[q] : make_uint4(0, 0, 0, 0);
             }
+        };
+        fetch(nx, a0 / PER);
+        for (uint32_t qb = a0 / PER; qb < q1; qb += YS_NT * YS_UNROLL) {
+#pragma unroll
+            for (int u = 0; u < YS_UNROLL; ++u) v[u] = nx[u];
+            if (qb + YS_NT * YS_UNROLL < q1) fetch(nx, qb + YS_NT * YS_UNROLL);
 #pragma unroll
             for (int u = 0; u < YS_UNROLL; ++u) {
                 if (qb + u * YS_NT + tid >= q1) continue;
                 const uint32_t word[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                uint32_t run_bin = NONE, run_len = 0;
-                auto step = [&](uint32_t bin) {
-                    if (bin == run_bin) {
-                        ++run_len;
-                    } else {
-                        if (run_bin < NB) atomicAdd(&h[run_bin], run_len);
-                        run_bin = bin;
-                        run_len = 1;
-                    }
-                };
+                uint32_t e[PER];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if constexpr (sizeof(ET) == 2) {
-                        step(bin_of(word[c] & 0xFFFFu));
-                        step(bin_of(word[c] >> 16));
-                    } else {
-                        step(bin_of(word[c]));
+                    if constexpr (sizeof(ET) == 2)
+                        e[2 * c] = word[c] & 0xFFFFu, e[2 * c + 1] = word[c] >> 16;
+                    else
+                        e[c] = word[c];
+                }
+                bool any_pair = false;
+#pragma unroll
+                for (uint32_t c = 0; c + 1 < PER; ++c) any_pair |= e[c] == e[c + 1];
+                if (!any_pair) {  // (all but a few lanes in a thousand on random sequence)
+#pragma unroll
+                    for (uint32_t c = 0; c < PER; ++c) add1(bin_of(e[c]));
+                } else {
+                    // the lane's hot bin: the value of an adjacent equal pair of this load, unless the load still holds
+                    // the one chosen before
+                    uint32_t rep = NONE;
+                    bool has_hot = false;
+#pragma unroll
+                    for (uint32_t c = 0; c < PER; ++c) {
+                        has_hot |= e[c] == hot_v;
+                        if (c + 1 < PER && e[c] == e[c + 1]) rep = e[c];
+                    }
+                    if (!has_hot) {
+                        const uint32_t hb = bin_of(hot_v);
+                        if (hot_n && hb < NB) atomicAdd(&h[hb], hot_n);
+                        hot_v = rep;
+                        hot_n = 0;
+                    }
+#pragma unroll
+                    for (uint32_t c = 0; c < PER; ++c) {
+                        if (e[c] == hot_v)
+                            ++hot_n;
+                        else
+                            add1(bin_of(e[c]));
                     }
                 }
-                if (run_bin < NB) atomicAdd(&h[run_bin], run_len);
             }
+        }
+        if (hot_n) {
+            const uint32_t hb = bin_of(hot_v);
+            if (hb < NB) atomicAdd(&h[hb], hot_n);
         }
     } else {
         for (uint32_t i = begin + tid; i < end; i += YS_NT) add1(bin_of(ent[i]));
@@ -3619,9 +3679,9 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         if (int rc = scan_tilehist(hist, nt0, bsum, &scal[0], s, regs0, c_E)) return rc;
         pt.mark("k_scan");
         if (two_pass)
-            hipLaunchKernelGGL((k_yscatter<uint32_t, 1024>), dim3(nt0 < (uint32_t)YS32_BLOCKS ? nt0 : (uint32_t)YS32_BLOCKS), dim3(1024), 0, s, a, c_hist, n_words8, nt0, entA);
+            hipLaunchKernelGGL((k_yscatter<uint32_t, 1024, 1>), dim3(nt0 < (uint32_t)YS32_BLOCKS ? nt0 : (uint32_t)YS32_BLOCKS), dim3(1024), 0, s, a, c_hist, (const uint32_t *)regs0, n_words8, nt0, entA);
         else  // one pass: 2-byte payloads
-            hipLaunchKernelGGL((k_yscatter<uint16_t, 1024>), dim3(nt0 < (uint32_t)YS16_BLOCKS ? nt0 : (uint32_t)YS16_BLOCKS), dim3(1024), 0, s, a, c_hist, n_words8, nt0, (uint16_t *)entA);
+            hipLaunchKernelGGL((k_yscatter<uint16_t, YS16_NT, 1024 / YS16_NT>), dim3(nt0 < (uint32_t)YS16_BLOCKS ? nt0 : (uint32_t)YS16_BLOCKS), dim3(YS16_NT), 0, s, a, c_hist, (const uint32_t *)regs0, n_words8, nt0, (uint16_t *)entA);
         pt.mark("k_scatter<bases,y>");
         const uint32_t *sorted = entA, *final_regions = regs0;
         if (two_pass) {
