@@ -441,6 +441,7 @@ __global__ __launch_bounds__(YL_NT) void k_count_y_lds(BasesArgs a, int32_t *cou
 #ifndef YS16_NT
 #define YS16_NT 1024
 #endif
+
 #ifndef YS32_BLOCKS
 #define YS32_BLOCKS 256
 #endif
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(NT) void k_hist_entries(const ET *ent, const uint32
     constexpr bool NARROW = sizeof(ET) == 4;
     constexpr int RADIX = 1 << BITS;  // (shadows the 256 of the file scope: this kernel's number of bins)
     static_assert(RADIX <= NT && (!NARROW || BITS == 8), "one thread per bin when a tile's row is written");
-    __shared__ uint32_t h[2][NW][RADIX];
+    __shared__ uint32_t h[2][RADIX];  // one table per tile for all waves (see k_hist_words_y)
     const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
     const uint32_t E = *p_count;
     const uint32_t per = (n_tiles + gridDim.x - 1) / gridDim.x;
@@ -716,11 +717,11 @@ __global__ __launch_bounds__(NT) void k_hist_entries(const ET *ent, const uint32
         }
     };
     load_tile(t0);
-    for (uint32_t i = tid; i < NW * RADIX; i += NT) (&h[0][0][0])[i] = 0;
+    for (uint32_t i = tid; i < 2 * RADIX; i += NT) (&h[0][0])[i] = 0;
     lds_sync();
     for (uint32_t tile = t0; tile < t1; ++tile) {
-        uint32_t(*const hc)[RADIX] = h[(tile - t0) & 1u];
-        uint32_t(*const hn)[RADIX] = h[((tile - t0) & 1u) ^ 1u];
+        uint32_t *const hc = h[(tile - t0) & 1u];
+        uint32_t *const hn = h[((tile - t0) & 1u) ^ 1u];
         const uint64_t base = (uint64_t)tile * TILE;
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
@@ -730,19 +731,13 @@ __global__ __launch_bounds__(NT) void k_hist_entries(const ET *ent, const uint32
                 d = (uint32_t)e[j] >> 24;
             else
                 d = (entry_key((u64)e[j]) >> shift) & (uint32_t)(RADIX - 1);
-            if (i < E) atomicAdd(&hc[w][d], 1u);
+            if (i < E) atomicAdd(&hc[d], 1u);
         }
         if (tile + 1 < t1) load_tile(tile + 1);  // e[] is free again
-        for (uint32_t i = tid; i < NW * RADIX; i += NT) (&hn[0][0])[i] = 0;  // the other table, for the next tile
+        if (tid < RADIX) hn[tid] = 0;  // the other table, for the next tile
         lds_sync();
-        if (tid < RADIX) {
-            uint32_t s = 0;
-#pragma unroll
-            for (int i = 0; i < NW; ++i) s += hc[i][tid];
-            tilehist[(uint64_t)tile * RADIX + tid] = s;
-        }
-        // the next tile zeroes hc right after its atomics (which go to hn): the readers above must be done first
-        lds_sync();
+        // (no second barrier: thread tid zeroes hc[tid] itself, in the next iteration, after this read)
+        if (tid < RADIX) tilehist[(uint64_t)tile * RADIX + tid] = hc[tid];
     }
 }
 
@@ -2192,8 +2187,8 @@ __global__ __launch_bounds__(NT) void k_heads_hist(const uint32_t *ent, const ui
         if (tile + 1 < t1) load_tile(tile + 1);
         if (tid < RADIX) hn[tid] = 0u;  // the other table, for the next tile
         lds_sync();
+        // (no second barrier: the next tile's atomics go to hn; hc[tid] is zeroed a tile later by the thread that reads it here)
         if (tid < RADIX) tilehist[(uint64_t)tile * RADIX + tid] = hc[tid];
-        lds_sync();  // the next tile's atomics go to hn; hc is zeroed a tile later, after these reads
     }
 }
 
@@ -3663,7 +3658,10 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
         // a slice's workgroup counts at most `cap` entries itself: a little over the mean range (the longest workgroup sets
         // the kernel's time when there is one wave of them), at least two overflow chunks
         uint64_t cap64 = (uint64_t)nt * TILE / n_ranges;
-        cap64 += cap64 / 4;  // 1.25 x the mean range (of positions: >= entries)
+        if (K <= 11)
+            cap64 /= 2;  // one workgroup per region and CU: half the mean, the rest balanced over the overflow grid (y10: 1.27 -> 0.89 ms per 2^31 positions)
+        else
+            cap64 += cap64 / 4;  // 1.25 x the mean range (of positions: >= entries): at K >= 12 the queue's atomic flush costs more than it balances
         if (cap64 < 2 * (uint64_t)YS_OVF_CHUNK) cap64 = 2 * (uint64_t)YS_OVF_CHUNK;
         if (kn.y_cap) cap64 = kn.y_cap;  // knob: tests
         const uint32_t cap = (uint32_t)(cap64 > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap64);
@@ -3690,6 +3688,8 @@ int count_y(const uint32_t *d_bases, size_t bases_words, const uint32_t *d_valid
             if (int rc = scan_tilehist(hist, nt, bsum, &scal[4], s, regs1, c_E)) return rc;
             pt.mark("k_scan");
             // this pass keeps the order of the byte pass 0 sorted on (k_count_y_sorted searches a region by it): mode 2
+            // (round 3 built this pass like k_yscatter as well -- 16,384- and 8192-entry tiles, 512 / 1024 threads, known
+            // digit counts, one atomic per entry: 26.1 - 32.3 ms per step of y14 against 26.3 ms for this kernel; removed)
             hipLaunchKernelGGL((k_scatter<false, uint32_t, 2>), pgrid, block, 0, s, a, (const uint32_t *)entA, c_E, 8, c_hist, nt, entB,
                                (const uint32_t *)regs0);
             pt.mark("k_scatter<entries>");
