@@ -16,12 +16,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <sys/mman.h>
+#include <sys/stat.h>
 
 #include <hip/hip_runtime_api.h>
 
@@ -194,10 +197,70 @@ struct DevStore {
     }
 };
 
+// First touch of the caller's output arrays on a few threads of their own, started when a file-level call begins and
+// stopped before its D2H stage.  numpy.zeros hands out untouched pages: faulting 4.6 GB in (the kernel zeroes every page)
+// costs 60-100 ms on the GPU box (tools/mb_touch.c), as much as the PCIe transfer it used to be paid inside.  Pages are
+// touched with a read and a write-back of the same byte, so whatever the caller has in the arrays stays; nobody else
+// writes them before finish().  Huge pages are asked for first (512 times fewer faults where the system grants them).
+int prefault_threads() { return std::max(1, kmers::host_threads() / 4); }
+
+class Prefault {
+    struct Range { char *p; size_t bytes; };
+    std::vector<Range> ranges_;
+    std::vector<std::thread> threads_;
+    std::atomic<size_t> next_{0};
+    std::atomic<bool> stop_{false};
+    static constexpr size_t BLOCK = (size_t)2 << 20;
+    size_t blocks_of(const Range &r) const { return (r.bytes + BLOCK - 1) / BLOCK; }
+    void work() {
+        size_t total = 0;
+        for (const Range &r : ranges_) total += blocks_of(r);
+        for (;;) {
+            size_t b = next_.fetch_add(1, std::memory_order_relaxed);
+            if (b >= total || stop_.load(std::memory_order_relaxed)) return;
+            size_t ri = 0;
+            while (b >= blocks_of(ranges_[ri])) b -= blocks_of(ranges_[ri++]);
+            const Range &r = ranges_[ri];
+            char *lo = r.p + b * BLOCK, *hi = std::min(r.p + r.bytes, lo + BLOCK);
+            const uintptr_t a = ((uintptr_t)lo + BLOCK - 1) & ~(uintptr_t)(BLOCK - 1);
+            if (a + BLOCK <= (uintptr_t)r.p + r.bytes) (void)madvise((void *)a, BLOCK, MADV_HUGEPAGE);  // the aligned block that starts in here
+            for (char *q = lo; q < hi; q += 4096) {
+                volatile char *v = q;
+                const char c = *v;
+                *v = c;
+            }
+            volatile char *last = hi - 1;
+            const char c = *last;
+            *last = c;
+        }
+    }
+
+public:
+    Prefault() = default;
+    Prefault(const Prefault &) = delete;
+    Prefault &operator=(const Prefault &) = delete;
+    ~Prefault() { finish(); }
+    void add(void *p, size_t bytes) {
+        if (p && bytes) ranges_.push_back(Range{(char *)p, bytes});
+    }
+    void start(int n_threads) {
+        if (ranges_.empty()) return;
+        for (int i = 0; i < n_threads; ++i) threads_.emplace_back([this] { work(); });
+    }
+    void finish() {  // after this no thread of ours touches the arrays
+        stop_.store(true, std::memory_order_relaxed);
+        for (std::thread &t : threads_) t.join();
+        threads_.clear();
+    }
+};
+
 int count_files(int n_files, const char *fnames[], int K, int *counts, int mode) {
     if (K < 1 || K > 16 || !counts || n_files < 0) return KMERS_ERR_BAD_ARG;
     StageClock clk;
     StoreGuard g;
+    Prefault pre;
+    pre.add(counts, ((size_t)1 << (2 * K)) * 4);
+    pre.start(prefault_threads());
     if (int rc = kmers_store_ingest(n_files, fnames, mode, 0, 0, 1, &g.s)) return rc;
     clk.lap("host ingest");
     if (int rc = select_device()) return rc;
@@ -219,6 +282,7 @@ int count_files(int n_files, const char *fnames[], int K, int *counts, int mode)
                              dc.as<int32_t>(), d_ws.p, ws_bytes, s))
         return rc;
     clk.lap("histogram (GPU, enqueue)");
+    pre.finish();
     // the reference only ever increments the caller's array (src/libkmers.cpp:213-216): add, do not overwrite
     if (int rc = d2h_chunks(dc.p, M * 4, s, [&](size_t off, const char *src, size_t n) {
             int *dst = counts + off / 4;
@@ -237,7 +301,7 @@ constexpr uint64_t X_MAX_POS = 0xFFFF0000ull, X_MAX_REC = 0x7FFFFFFFull;  // one
 // One store -> CSR in host arrays (data / col_ind hold min(max_size, windows) entries, row_ind 4^K + 1); columns are
 // numbered from the store's first record.
 int build_store(const kmers_store *st, int K, uint64_t max_size, float *data, uint64_t *row_ind, uint64_t *col_ind, uint64_t *nnz,
-                StageClock &clk) {
+                StageClock &clk, Prefault *pre = nullptr) {
     const uint64_t n_pos = kmers_store_n_pos(st), n_rec = kmers_store_n_rec(st);
     if (n_pos > X_MAX_POS || n_rec > X_MAX_REC) return KMERS_ERR_TOO_LARGE;
     const uint64_t M = 1ull << (2 * K);
@@ -264,6 +328,7 @@ int build_store(const kmers_store *st, int K, uint64_t max_size, float *data, ui
     }
     if (rc) return rc;
     clk.lap("build X (GPU)");
+    if (pre) pre->finish();
     // PCIe bounds this stage (config 2: 4.6 GB of CSR): indices travel as 32-bit values -- narrowed on the device into the
     // workspace, which is free again, widened by the host threads as they move each chunk into the caller's uint64
     // arrays -- a third fewer bytes on the link.  (Every value fits: nnz and the column numbers of one call are < 2^32.)
@@ -337,6 +402,19 @@ int build_files(int n_files, const char *fnames[], int K, int L, int mode, float
     StageClock clk;
     const uint64_t M = 1ull << (2 * K);
     uint64_t n_pos, n_rec_total, n_ranges;
+    // the output arrays are faulted in while the files are parsed and the GPU builds: row_ind whole, of data / col_ind
+    // what the files can fill at most (every non-zero has a base of its own in them; max_size may be far larger)
+    uint64_t file_bytes = 0;
+    for (int f = 0; f < n_files; ++f) {
+        struct stat sb;
+        if (fnames && fnames[f] && stat(fnames[f], &sb) == 0 && sb.st_size > 0) file_bytes += (uint64_t)sb.st_size;
+    }
+    const uint64_t pre_n = std::min(max_size, file_bytes);
+    Prefault pre;
+    pre.add(row_ind, (size_t)(M + 1) * 8);
+    pre.add(col_ind, (size_t)pre_n * 8);
+    pre.add(data, (size_t)pre_n * 4);
+    pre.start(prefault_threads());
     {
         StoreGuard g;
         if (int rc = kmers_store_ingest(n_files, fnames, mode, L, 0, 1, &g.s)) return rc;
@@ -350,11 +428,12 @@ int build_files(int n_files, const char *fnames[], int K, int L, int mode, float
             if (v < X_MAX_POS) chunk_pos = v;
         if (n_pos <= chunk_pos && n_rec_total <= X_MAX_REC) {
             uint64_t nz = 0;
-            if (int rc = build_store(g.s, K, max_size, data, row_ind, col_ind, &nz, clk)) return rc;
+            if (int rc = build_store(g.s, K, max_size, data, row_ind, col_ind, &nz, clk, &pre)) return rc;
             *nnz = nz;
             *n_cols = (int)n_rec_total;
             return KMERS_OK;
         }
+        pre.finish();
         // more positions than one device call indexes: contiguous record ranges (the ingest's shards, balanced by
         // positions), one matrix each, interleaved row by row at the end (columns ascend from range to range)
         const uint64_t *rs = kmers_store_rec_start(g.s);

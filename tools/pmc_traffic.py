@@ -25,8 +25,10 @@ LABEL = [  # kernel symbol (regex) -> the label of bench.py's per-kernel table
     (r"k_dd<true", "k_dd<scatter>"),
     (r"k_final_scatter", "k_final_scatter"),
     (r"k_scatter<true, unsigned int, true|k_yscatter", "k_scatter<bases,y>"),
-    (r"k_scatter<true", "k_scatter<bases>"),
-    (r"k_scatter<false", "k_scatter<entries>"),
+    (r"k_scatter<true|k_xscatter0", "k_scatter<bases>"),
+    (r"k_scatter<false|k_scatter_wide", "k_scatter<entries>"),
+    (r"k_heads_hist", "k_heads_hist"),
+    (r"k_emit", "k_emit"),
     (r"k_hist_words_y", "k_hist_words_y"),
     (r"k_hist_bases", "k_hist_bases"),
     (r"k_hist_entries", "k_hist_entries"),
