@@ -45,6 +45,7 @@
 #include <thread>
 #include <unistd.h>
 #include <zlib.h>
+#include <immintrin.h>
 
 #include <hip/hip_runtime_api.h>
 
@@ -383,6 +384,16 @@ bool analyse_records(const FileView &f, const std::vector<size_t> &hdrs, size_t 
 // ---- streaming packer: appends bases at consecutive positions of the store arrays.
 // Words completely covered by one piece are written with plain stores; the first and last word a piece
 // touches may be shared with a neighbouring piece handled by another thread and are OR-ed in atomically.
+// (KMERS_NO_SIMD: the scalar packer, for same-input comparisons of the two in tests)
+const bool g_have_ssse3 = [] {
+#if defined(__HIP_DEVICE_COMPILE__)  // (hipcc also runs this file through its device pass)
+    return false;
+#else
+    __builtin_cpu_init();
+    return __builtin_cpu_supports("ssse3") && !getenv("KMERS_NO_SIMD");
+#endif
+}();
+
 class StreamPacker {
   public:
     StreamPacker(uint32_t *bases, uint32_t *valid, uint64_t pos) : B(bases), V(valid), pos_(pos) {
@@ -390,6 +401,70 @@ class StreamPacker {
         v_shared_ = (pos & 31) != 0;
     }
     void push(const uint8_t *s, size_t n) {
+        if (g_have_ssse3)
+            push_simd(s, n);
+        else
+            push_scalar(s, n);
+    }
+
+  private:
+    // 16 bytes -> the 32-bit word of their 2-bit codes (first base in the top bits, 0 for a byte that is no base) and
+    // the 16 validity bits (bit k = byte k is one of ACGT).  The low nibbles of 'A' 'C' 'G' 'T' are 1, 3, 7, 4: one
+    // shuffle looks the code up, a second one the character that nibble stands for, and a byte is valid iff it IS that
+    // character (the nibbles that stand for nothing expect a byte their own low nibble rules out).
+    __attribute__((target("ssse3"))) static void conv16(const uint8_t *p, uint32_t &w, uint32_t &m) {
+        const __m128i x = _mm_loadu_si128(reinterpret_cast<const __m128i *>(p));
+        const __m128i lo = _mm_and_si128(x, _mm_set1_epi8(0x0F));
+        const __m128i lut_code = _mm_setr_epi8(0, 0, 0, 1, 3, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0);
+        const __m128i lut_char = _mm_setr_epi8((char)0xFF, 'A', 0, 'C', 'T', 0, 0, 'G', 0, 0, 0, 0, 0, 0, 0, 0);
+        const __m128i ok = _mm_cmpeq_epi8(x, _mm_shuffle_epi8(lut_char, lo));
+        const __m128i code = _mm_and_si128(_mm_shuffle_epi8(lut_code, lo), ok);
+        m = (uint32_t)_mm_movemask_epi8(ok);
+        const __m128i t = _mm_maddubs_epi16(code, _mm_set1_epi16(0x0104));       // pairs: c0 * 4 + c1 (0x04 is the even byte)
+        const __m128i u = _mm_madd_epi16(t, _mm_set1_epi32(0x00010010));          // fours: t0 * 16 + t1, one byte's worth per dword
+        const __m128i g = _mm_shuffle_epi8(u, _mm_setr_epi8(12, 8, 4, 0, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1));
+        w = (uint32_t)_mm_cvtsi128_si32(g);
+    }
+    // r <= 16 bases (the top 2 r bits of w, the low r bits of m) behind what is there
+    void append(uint32_t w, uint32_t m, uint32_t r) {
+        bacc_ |= (uint64_t)w << (32 - bfill_);
+        bfill_ += 2 * r;
+        if (bfill_ >= 32) {
+            store(B + bword_++, (uint32_t)(bacc_ >> 32), b_shared_);
+            b_shared_ = false;
+            bacc_ <<= 32;
+            bfill_ -= 32;
+        }
+        vacc_ |= (uint64_t)m << vfill_;
+        vfill_ += r;
+        if (vfill_ >= 32) {
+            store(V + vword_++, (uint32_t)vacc_, v_shared_);
+            v_shared_ = false;
+            vacc_ >>= 32;
+            vfill_ -= 32;
+        }
+    }
+    __attribute__((target("ssse3"))) void push_simd(const uint8_t *s, size_t n) {
+        if (!simd_) {  // (the first push decides: a packer never mixes the two forms)
+            simd_ = true;
+            bword_ = pos_ / 16, bfill_ = 2 * (uint32_t)(pos_ & 15);
+            vword_ = pos_ / 32, vfill_ = (uint32_t)(pos_ & 31);
+        }
+        size_t i = 0;
+        uint32_t w, m;
+        for (; n - i >= 16; i += 16) {
+            conv16(s + i, w, m);
+            append(w, m, 16);
+        }
+        if (i < n) {  // the tail through a zero-padded copy (zero is no base: code 0, validity 0)
+            alignas(16) uint8_t buf[16] = {0};
+            memcpy(buf, s + i, n - i);
+            conv16(buf, w, m);
+            append(w, m, (uint32_t)(n - i));
+        }
+        pos_ += n;
+    }
+    void push_scalar(const uint8_t *s, size_t n) {
         uint64_t pos = pos_;
         uint32_t bw = bw_, vw = vw_;
         size_t i = 0;
@@ -449,7 +524,19 @@ class StreamPacker {
         bw_ = bw;
         vw_ = vw;
     }
+
+  public:
     void finish() {
+        if (simd_) {
+            if (bfill_) store(B + bword_, (uint32_t)(bacc_ >> 32), true);
+            if (vfill_) store(V + vword_, (uint32_t)vacc_, true);
+            bacc_ = vacc_ = 0;
+            bfill_ = vfill_ = 0;
+            simd_ = false;
+            b_shared_ = (pos_ & 15) != 0;
+            v_shared_ = (pos_ & 31) != 0;
+            return;
+        }
         if (pos_ & 15) store(B + pos_ / 16, bw_, true);
         if (pos_ & 31) store(V + pos_ / 32, vw_, true);
         bw_ = vw_ = 0;
@@ -467,6 +554,10 @@ class StreamPacker {
     uint64_t pos_;
     uint32_t bw_ = 0, vw_ = 0;
     bool b_shared_, v_shared_;
+    // the SIMD form's state: bases top-aligned in bacc_ (bfill_ < 32 bits pending), validity from bit 0 of vacc_
+    bool simd_ = false;
+    uint64_t bacc_ = 0, vacc_ = 0, bword_ = 0, vword_ = 0;
+    uint32_t bfill_ = 0, vfill_ = 0;
 };
 
 void pack_piece(const Piece &pc, uint64_t dst, uint32_t *bases, uint32_t *valid) {

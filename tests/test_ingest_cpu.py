@@ -355,3 +355,46 @@ def test_multi_member_fastq_gz_is_faster_on_more_threads(tmp_path, monkeypatch):
         times[threads] = best
         assert n == 4 * 150_000 * 100
     assert times["8"] < 0.85 * times["1"], times           # (measured here: 0.74 s -> 0.34 s; the line scan stays serial)
+
+
+def test_simd_packer_equals_scalar_packer(tmp_path):
+    """The SSSE3 packer (16 bytes per step, any bit alignment of the destination) against the byte-at-a-time one
+    (KMERS_NO_SIMD=1, read when the library is loaded: hence two child processes) on ragged files that hold every byte
+    value: the packed bases, the validity mask and the record table must be the same words."""
+    import hashlib
+    import subprocess
+    import sys
+    rng = np.random.default_rng(99)
+    paths = []
+    for i in range(6):
+        p = tmp_path / f"f{i}.fsa"
+        p.write_bytes(kmtest.fuzz_fasta_bytes(100 + i))
+        paths.append(str(p))
+    p = tmp_path / "allbytes.fsa"      # every byte value in sequence lines of every length 1..70
+    with open(p, "wb") as f:
+        for n in range(1, 71):
+            f.write(b">r%d\n" % n)
+            line = bytes(rng.integers(0, 256, size=n, dtype=np.uint8)).replace(b"\n", b"A").replace(b">", b"C")
+            f.write(line + b"\n" + bytes(rng.choice(np.frombuffer(b"ACGTacgtN", np.uint8), size=3 * n)) + b"\n")
+    paths.append(str(p))
+    code = ("import sys, hashlib, os\n"
+            "os.environ['KMERS_NO_TORCH'] = '1'\n"
+            f"sys.path.insert(0, {kmtest.ROOT!r})\n"
+            "from kmers_amd.store import Store, MODE_X, MODE_Y_FASTA, MODE_FASTA_PY\n"
+            "h = hashlib.sha256()\n"
+            "for mode in (MODE_X, MODE_Y_FASTA):\n"
+            "    for p in sys.argv[1:]:\n"
+            "        st = Store([p], mode)\n"
+            "        for a in (st.bases, st.valid, st.rec_start):\n"
+            "            h.update(a.tobytes())\n"
+            "st = Store(sys.argv[1:], MODE_X)\n"
+            "h.update(st.bases.tobytes()); h.update(st.valid.tobytes())\n"
+            "print(h.hexdigest())\n")
+    out = {}
+    for simd in ("1", "0"):
+        env = dict(os.environ)
+        env.pop("KMERS_NO_SIMD", None)
+        if simd == "0":
+            env["KMERS_NO_SIMD"] = "1"
+        out[simd] = subprocess.check_output([sys.executable, "-c", code] + paths, env=env, text=True).strip()
+    assert out["1"] == out["0"] and len(out["1"]) == 64
