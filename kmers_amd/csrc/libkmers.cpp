@@ -197,11 +197,14 @@ struct DevStore {
     }
 };
 
-// First touch of the caller's output arrays on a few threads of their own, started when a file-level call begins and
-// stopped before its D2H stage.  numpy.zeros hands out untouched pages: faulting 4.6 GB in (the kernel zeroes every page)
-// costs 60-100 ms on the GPU box (tools/mb_touch.c), as much as the PCIe transfer it used to be paid inside.  Pages are
-// touched with a read and a write-back of the same byte, so whatever the caller has in the arrays stays; nobody else
-// writes them before finish().  Huge pages are asked for first (512 times fewer faults where the system grants them).
+// First touch of the caller's output arrays on a few threads of their own, from the start of a file-level call to its
+// end.  numpy.zeros hands out untouched pages; faulting 4.6 GB in costs 60-100 ms on the GPU box whatever the number of
+// threads above four (the kernel zeroes every page: memory-bound, tools/mb_touch.c) -- as much as the PCIe transfer it
+// used to be paid inside.  Under the parse and the GPU build (compute-bound) about half of it disappears; started
+// only after the parse it competes with the copy for the same memory bandwidth and hides nothing (measured both ways).  A page is touched with an
+// atomic OR of zero into one of its bytes: it changes nothing and, being one indivisible read-modify-write, cannot
+// undo a store the copy threads make to the same byte at the same time, so the two may overlap freely.  Huge pages are
+// asked for first (512 times fewer faults where the system grants them).
 int prefault_threads() { return std::max(1, kmers::host_threads() / 4); }
 
 class Prefault {
@@ -224,14 +227,8 @@ class Prefault {
             char *lo = r.p + b * BLOCK, *hi = std::min(r.p + r.bytes, lo + BLOCK);
             const uintptr_t a = ((uintptr_t)lo + BLOCK - 1) & ~(uintptr_t)(BLOCK - 1);
             if (a + BLOCK <= (uintptr_t)r.p + r.bytes) (void)madvise((void *)a, BLOCK, MADV_HUGEPAGE);  // the aligned block that starts in here
-            for (char *q = lo; q < hi; q += 4096) {
-                volatile char *v = q;
-                const char c = *v;
-                *v = c;
-            }
-            volatile char *last = hi - 1;
-            const char c = *last;
-            *last = c;
+            for (char *q = lo; q < hi; q += 4096) (void)__atomic_fetch_or(q, (char)0, __ATOMIC_RELAXED);
+            (void)__atomic_fetch_or(hi - 1, (char)0, __ATOMIC_RELAXED);
         }
     }
 
@@ -282,7 +279,6 @@ int count_files(int n_files, const char *fnames[], int K, int *counts, int mode)
                              dc.as<int32_t>(), d_ws.p, ws_bytes, s))
         return rc;
     clk.lap("histogram (GPU, enqueue)");
-    pre.finish();
     // the reference only ever increments the caller's array (src/libkmers.cpp:213-216): add, do not overwrite
     if (int rc = d2h_chunks(dc.p, M * 4, s, [&](size_t off, const char *src, size_t n) {
             int *dst = counts + off / 4;
@@ -292,6 +288,7 @@ int count_files(int n_files, const char *fnames[], int K, int *counts, int mode)
             });
         }))
         return rc;
+    pre.finish();
     clk.lap("counts += (D2H)");
     return KMERS_OK;
 }
@@ -328,7 +325,6 @@ int build_store(const kmers_store *st, int K, uint64_t max_size, float *data, ui
     }
     if (rc) return rc;
     clk.lap("build X (GPU)");
-    if (pre) pre->finish();
     // PCIe bounds this stage (config 2: 4.6 GB of CSR): indices travel as 32-bit values -- narrowed on the device into the
     // workspace, which is free again, widened by the host threads as they move each chunk into the caller's uint64
     // arrays -- a third fewer bytes on the link.  (Every value fits: nnz and the column numbers of one call are < 2^32.)
@@ -375,6 +371,7 @@ int build_store(const kmers_store *st, int K, uint64_t max_size, float *data, ui
         }
         if (int e = d2h_copy(data, d_data.p, nz * 4, s)) return e;
     }
+    if (pre) pre->finish();  // (what it has not reached by now the copy has touched itself)
     clk.lap("D2H into the host arrays");
     *nnz = nz;
     return KMERS_OK;

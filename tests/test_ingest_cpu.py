@@ -360,7 +360,8 @@ def test_multi_member_fastq_gz_is_faster_on_more_threads(tmp_path, monkeypatch):
 def test_simd_packer_equals_scalar_packer(tmp_path):
     """The SSSE3 packer (16 bytes per step, any bit alignment of the destination) against the byte-at-a-time one
     (KMERS_NO_SIMD=1, read when the library is loaded: hence two child processes) on ragged files that hold every byte
-    value: the packed bases, the validity mask and the record table must be the same words."""
+    value: the packed bases, the validity mask and the record table must be the same words.  Also with the arrays
+    poisoned before packing (KMERS_INGEST_POISON): only the words between pieces are zeroed, the rest must be written."""
     import hashlib
     import subprocess
     import sys
@@ -391,10 +392,13 @@ def test_simd_packer_equals_scalar_packer(tmp_path):
             "h.update(st.bases.tobytes()); h.update(st.valid.tobytes())\n"
             "print(h.hexdigest())\n")
     out = {}
-    for simd in ("1", "0"):
+    for simd in ("1", "0", "poison", "poison0"):    # poison: the arrays start as 0xA5 instead of whatever malloc gave
         env = dict(os.environ)
         env.pop("KMERS_NO_SIMD", None)
-        if simd == "0":
+        env.pop("KMERS_INGEST_POISON", None)
+        if simd in ("0", "poison0"):
             env["KMERS_NO_SIMD"] = "1"
+        if simd.startswith("poison"):
+            env["KMERS_INGEST_POISON"] = "1"
         out[simd] = subprocess.check_output([sys.executable, "-c", code] + paths, env=env, text=True).strip()
-    assert out["1"] == out["0"] and len(out["1"]) == 64
+    assert out["1"] == out["0"] == out["poison"] == out["poison0"] and len(out["1"]) == 64
