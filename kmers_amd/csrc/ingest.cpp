@@ -39,6 +39,7 @@
 #include <fcntl.h>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -746,14 +747,62 @@ bool read_fastq_sequence(const char *path, std::vector<uint8_t> &seq, bool membe
     return true;
 }
 
+// Pinned store arrays are handed back to a small cache instead of the driver: a fresh hipHostMalloc of config 2's 150 MB
+// costs ~6 ms per file-level call, most of it the first touch of its pages (whichever stage writes them first pays).
+// At most 4 blocks / 1 GiB are kept; a block serves requests down to half its size.
+struct PinCache {
+    struct Block { void *p; size_t bytes; };
+    std::mutex mu;
+    std::vector<Block> free_blocks;
+    std::vector<Block> live;  // sizes of the pinned blocks handed out (free_words gets the pointer only)
+    static constexpr size_t MAX_BLOCKS = 4, MAX_BYTES = (size_t)1 << 30;
+    void *take(size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t best = free_blocks.size();
+        for (size_t i = 0; i < free_blocks.size(); ++i)
+            if (free_blocks[i].bytes >= bytes && free_blocks[i].bytes / 2 <= bytes &&
+                (best == free_blocks.size() || free_blocks[i].bytes < free_blocks[best].bytes))
+                best = i;
+        if (best == free_blocks.size()) return nullptr;
+        const Block b = free_blocks[best];
+        free_blocks.erase(free_blocks.begin() + (long)best);
+        live.push_back(b);
+        return b.p;
+    }
+    void note(void *p, size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu);
+        live.push_back(Block{p, bytes});
+    }
+    bool give(void *p) {  // true: kept; false: the caller frees it
+        std::lock_guard<std::mutex> lk(mu);
+        size_t at = live.size();
+        for (size_t i = 0; i < live.size(); ++i)
+            if (live[i].p == p) at = i;
+        if (at == live.size()) return false;
+        const Block b = live[at];
+        live.erase(live.begin() + (long)at);
+        size_t total = b.bytes;
+        for (const Block &f : free_blocks) total += f.bytes;
+        if (free_blocks.size() >= MAX_BLOCKS || total > MAX_BYTES) return false;
+        free_blocks.push_back(b);
+        return true;
+    }
+};
+PinCache g_pin_cache;
+
 void *alloc_words(size_t words, bool *pinned) {
     void *p = nullptr;
     *pinned = false;
     const size_t bytes = words * sizeof(uint32_t);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
+        if ((p = g_pin_cache.take(bytes)) != nullptr) {
+            *pinned = true;
+            return p;
+        }
         if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) {
             *pinned = true;
+            g_pin_cache.note(p, bytes);
             return p;
         }
         (void)hipGetLastError();
@@ -767,10 +816,11 @@ void *alloc_words(size_t words, bool *pinned) {
 
 void free_words(void *p, bool pinned) {
     if (!p) return;
-    if (pinned)
-        (void)hipHostFree(p);
-    else
+    if (pinned) {
+        if (!g_pin_cache.give(p)) (void)hipHostFree(p);
+    } else {
         free(p);
+    }
 }
 
 }  // namespace
