@@ -679,7 +679,9 @@ __global__ __launch_bounds__(BNT) void k_yscatter(BasesArgs a, const uint32_t *t
                         sent[slot] = (ET)(key & low_mask);
                     else
                         sent[slot] = (ET)((((key >> a.low_bits) >> 8) << 24) | (key & low_mask));
+#if !defined(YS_ABL) || YS_ABL < 2
                     saux[slot] = (uint8_t)d;
+#endif
                 }
             }
         }
@@ -689,7 +691,11 @@ __global__ __launch_bounds__(BNT) void k_yscatter(BasesArgs a, const uint32_t *t
             row_lo = row_hi;
         }
         const uint32_t tile_count = s_count[buf];
+#if !defined(YS_ABL)   // (YS_ABL: timing-only builds without the write-out, 2: also without the digit bytes)
         for (uint32_t i = tid; i < tile_count; i += BNT) out[gadj[buf][saux[i]] + i] = sent[i];
+#else
+        if (tile_count == 0xFFFFFFFFu) out[tid] = sent[tid] + saux[tid];
+#endif
         lds_sync();
     }
 }

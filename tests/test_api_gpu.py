@@ -126,3 +126,41 @@ def test_shards_merge_to_whole(product):
                       buf["col_ind"][:nnz].cpu().numpy().view(np.uint64)))
     d, r, c = merge_csr_parts(parts, 4 ** K)
     assert np.array_equal(r, row) and np.array_equal(c, col) and np.array_equal(d.view(np.uint32), data.view(np.uint32))
+
+
+def test_caller_arrays_keep_what_the_call_does_not_write(product, tmp_path):
+    """The file-level calls fault the caller's arrays in on threads of their own (Prefault, libkmers.cpp) while they
+    parse and build: whatever the arrays hold must survive -- X entries at and beyond nnz keep the caller's values, and y
+    is ADDED to counts that are not zero (reference src/libkmers.cpp:213-216)."""
+    import ctypes as C
+    from kmers_amd import _lib, synth
+    iso = str(tmp_path / "t.fsa")
+    synth.synth_transcriptome(iso, n_records=400, total_bases=900_000, seed=21)
+    K = 7
+    rc, data, row, col, n_cols = product.x([iso], K)
+    assert rc == 0
+    nnz = data.shape[0]
+    max_nz = os.path.getsize(iso)
+    lib = _lib.handle()
+    rng = np.random.default_rng(3)
+    d2 = rng.random(max_nz, dtype=np.float32) + 2.0
+    c2 = rng.integers(1 << 40, 1 << 41, size=max_nz, dtype=np.uint64)
+    r2 = np.full(4 ** K + 1, 77, np.uint64)
+    keep_d, keep_c = d2.copy(), c2.copy()
+    n, ncols = C.c_uint64(0), C.c_int(0)
+    for _ in range(3):      # (the touching threads race with the copy: more than one attempt at catching a lost store)
+        assert lib.fasta_to_kmers_csr(1, _lib.cfiles([iso]), K, 0, d2.ctypes.data_as(C.POINTER(C.c_float)),
+                                      r2.ctypes.data_as(C.POINTER(C.c_uint64)), c2.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      max_nz, C.byref(n), C.byref(ncols)) == 0
+        assert n.value == nnz and ncols.value == n_cols
+        assert np.array_equal(d2[:nnz].view(np.uint32), data.view(np.uint32)) and np.array_equal(c2[:nnz], col)
+        assert np.array_equal(r2, row)
+        assert np.array_equal(d2[nnz:], keep_d[nnz:]) and np.array_equal(c2[nnz:], keep_c[nnz:])
+    for Ky in (8, 12):
+        rc, y = product.y([iso], Ky)
+        assert rc == 0
+        start = rng.integers(-5, 1000, size=4 ** Ky).astype(np.int32)
+        acc = start.copy()
+        for rep in (1, 2):
+            rc, _ = product.y([iso], Ky, into=acc)
+            assert rc == 0 and np.array_equal(acc, start + rep * y)
