@@ -164,3 +164,16 @@ def test_caller_arrays_keep_what_the_call_does_not_write(product, tmp_path):
         for rep in (1, 2):
             rc, _ = product.y([iso], Ky, into=acc)
             assert rc == 0 and np.array_equal(acc, start + rep * y)
+
+
+def test_stage_record_of_the_file_level_calls(product, tmp_path):
+    """kmers_last_call_stages after fasta_to_kmers_csr / fasta_count_kmers: the four stages, in call order."""
+    from kmers_amd import _lib, synth
+    iso = str(tmp_path / "t.fsa")
+    synth.synth_transcriptome(iso, n_records=50, total_bases=60_000, seed=2)
+    assert product.x([iso], 6)[0] == 0
+    assert list(_lib.last_call_stages()) == ["host ingest", "H2D + device buffers", "build X (GPU)", "D2H into the host arrays"]
+    assert product.y([iso], 10)[0] == 0
+    st = _lib.last_call_stages()
+    assert list(st) == ["host ingest", "H2D + device buffers", "histogram (GPU, enqueue)", "counts += (D2H)"]
+    assert all(v >= 0.0 for v in st.values())

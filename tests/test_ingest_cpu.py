@@ -402,3 +402,25 @@ def test_simd_packer_equals_scalar_packer(tmp_path):
             env["KMERS_INGEST_POISON"] = "1"
         out[simd] = subprocess.check_output([sys.executable, "-c", code] + paths, env=env, text=True).strip()
     assert out["1"] == out["0"] == out["poison"] == out["poison0"] and len(out["1"]) == 64
+
+
+def test_debug_knob_and_stage_record_without_a_gpu(tmp_path):
+    """kmers_hip_debug_knob: known names return 0, an unknown one KMERS_ERR_BAD_ARG (-12), "reset" re-reads the
+    environment.  kmers_last_call_stages: a file-level call that fails for want of a device has still parsed the file, and
+    says so; a buffer too small for the record gets what fits, NUL-terminated."""
+    lib = _lib.handle()
+    for name in (b"y_atomics", b"y_cap", b"force_wide", b"x_path", b"old_pass0", b"x_chunk_pos", b"verbose", b"wide14"):
+        assert lib.kmers_hip_debug_knob(name, 1) == 0
+    assert lib.kmers_hip_debug_knob(b"no_such_knob", 1) == -12
+    assert lib.kmers_hip_debug_knob(b"reset", 0) == 0
+    p = tmp_path / "a.fsa"
+    p.write_text(">a\nACGTACGTAC\n")
+    y = np.zeros(4 ** 3, np.int32)
+    rc = lib.fasta_count_kmers(1, _lib.cfiles([str(p)]), 3, y.ctypes.data_as(C.POINTER(C.c_int)))
+    st = _lib.last_call_stages()
+    assert "host ingest" in st and st["host ingest"] >= 0.0
+    if rc != 0:                         # no GPU here: nothing after the parse ran
+        assert rc == -10 and list(st) == ["host ingest"] and not y.any()
+    small = C.create_string_buffer(8)
+    lib.kmers_last_call_stages(small, 8)
+    assert len(small.value) <= 7 and b"host ingest".startswith(small.value[:7])
