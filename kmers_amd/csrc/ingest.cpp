@@ -162,6 +162,40 @@ struct Piece {
 
 // A growing array of trivially copyable T without value-initialisation (10^7 read records make std::vector's
 // zero-fill and push_back a serial stage of their own).
+// The big per-call tables (one RecInfo and one Piece per record: ~200 MB for 2*10^6 reads) come from and go back to a
+// small process-wide cache: glibc maps blocks of this size afresh on every malloc and unmaps them on free, and touching
+// the new pages cost more than filling the tables.  At most 8 blocks / 1 GiB are kept; a block serves requests down to a
+// quarter of its size.
+struct HeapCache {
+    struct Block { void *p; size_t bytes; };
+    std::mutex mu;
+    std::vector<Block> blocks;
+    static constexpr size_t MIN_BYTES = (size_t)1 << 20, MAX_BLOCKS = 8, MAX_TOTAL = (size_t)1 << 30;
+    void *take(size_t need, size_t *got) {
+        if (need < MIN_BYTES) return nullptr;
+        std::lock_guard<std::mutex> lk(mu);
+        size_t best = blocks.size();
+        for (size_t i = 0; i < blocks.size(); ++i)
+            if (blocks[i].bytes >= need && blocks[i].bytes / 4 <= need && (best == blocks.size() || blocks[i].bytes < blocks[best].bytes))
+                best = i;
+        if (best == blocks.size()) return nullptr;
+        const Block b = blocks[best];
+        blocks.erase(blocks.begin() + (long)best);
+        *got = b.bytes;
+        return b.p;
+    }
+    bool give(void *p, size_t bytes) {  // false: not kept (the caller frees it)
+        if (bytes < MIN_BYTES) return false;
+        std::lock_guard<std::mutex> lk(mu);
+        size_t total = bytes;
+        for (const Block &b : blocks) total += b.bytes;
+        if (blocks.size() >= MAX_BLOCKS || total > MAX_TOTAL) return false;
+        blocks.push_back(Block{p, bytes});
+        return true;
+    }
+};
+HeapCache g_heap_cache;
+
 template <class T>
 struct RawVec {
     T *p = nullptr;
@@ -169,11 +203,18 @@ struct RawVec {
     RawVec() = default;
     RawVec(const RawVec &) = delete;
     RawVec &operator=(const RawVec &) = delete;
-    ~RawVec() { free(p); }
+    ~RawVec() {
+        if (p && !g_heap_cache.give(p, cap * sizeof(T))) free(p);
+    }
     T *grow(size_t more) {  // room for `more` new elements at the end; returns the first of them (nullptr: no memory)
         if (n + more > cap) {
             size_t nc = std::max(n + more, cap + cap / 2 + 16);
-            T *q = (T *)realloc(p, nc * sizeof(T));
+            T *q = nullptr;
+            if (!p) {
+                size_t got = 0;
+                if ((q = (T *)g_heap_cache.take(nc * sizeof(T), &got)) != nullptr) nc = got / sizeof(T);
+            }
+            if (!q) q = (T *)realloc(p, nc * sizeof(T));
             if (!q) return nullptr;
             p = q;
             cap = nc;

@@ -205,7 +205,10 @@ struct DevStore {
 // atomic OR of zero into one of its bytes: it changes nothing and, being one indivisible read-modify-write, cannot
 // undo a store the copy threads make to the same byte at the same time, so the two may overlap freely.  Huge pages are
 // asked for first (512 times fewer faults where the system grants them).
-int prefault_threads() { return std::max(1, kmers::host_threads() / 4); }
+int prefault_threads() {
+    if (const char *e = getenv("KMERS_PREFAULT_THREADS")) return std::max(0, atoi(e));  // (experiments; 0 = off)
+    return std::max(1, kmers::host_threads() / 4);
+}
 
 class Prefault {
     struct Range { char *p; size_t bytes; };
