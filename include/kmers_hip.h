@@ -175,6 +175,17 @@ int kmers_hip_debug_knob(const char *name, long long value);
  * partition kernels (s_memtime, wave 0 of every workgroup).  The product build returns KMERS_ERR_BAD_ARG. */
 int kmers_hip_debug_stamps(unsigned long long *out16, int reset);
 
+/* fasta_to_kmers_csr / fasta_to_kmers_csr_cat_subseq (include/libkmers.h) with int32 row_ind[4^K + 1] and col_ind[max_size]:
+ * for callers that narrow the indices anyway.  The reference's transcriptome_to_x builds a scipy csr_matrix from the
+ * uint64 arrays (kmerexpr/transcriptome_reader.py:33-37), and scipy stores int32 indices whenever they fit -- a serial
+ * 3 GB conversion for config 2, several times the whole GPU call; kmers_amd/transcriptome_reader.py uses this entry
+ * point instead.  The indices leave the device as 32-bit values in any case, so this also skips the widening and a
+ * third of the host memory written.  Same arguments, results and return codes as the two reference calls otherwise;
+ * KMERS_ERR_TOO_LARGE (without a message) when nnz or the column count is above 2^31 - 1 or the input needs the
+ * record-range route: the caller then uses the 64-bit call.  No counterpart in the reference. */
+int kmers_fasta_to_kmers_csr_i32(int n_files, const char *fnames[], int K, int L, int concatenate_subseq, float *data,
+                                 int32_t *row_ind, int32_t *col_ind, uint64_t max_size, uint64_t *nnz, int *n_cols);
+
 /* How many contiguous record ranges the file-level X calls cut an input into when it is above one device call's
  * limit (cap_pos positions; 0 = the built-in 2^32 - 65536): a record goes to range floor(start * n / n_pos), so a
  * range holds at most ceil(n_pos / n) + longest_rec_pos - 1 positions and n is chosen to keep that under the cap.
@@ -218,6 +229,11 @@ int kmers_csr_place_rows(uint64_t n, const uint64_t *src_start, const uint32_t *
  * write the file) or KMERS_ERR_BAD_ARG. */
 int kmers_npz_write_csr(const char *path, const float *data, const uint64_t *col_ind, const uint64_t *row_ind,
                         uint64_t nnz, uint64_t n_rows, uint64_t n_cols);
+
+/* The same file from int32 index arrays (what kmers_fasta_to_kmers_csr_i32 fills); KMERS_ERR_TOO_LARGE when the shape or
+ * nnz is above 2^31 - 1 (scipy would then store int64: use kmers_npz_write_csr). */
+int kmers_npz_write_csr_i32(const char *path, const float *data, const int32_t *col_ind, const int32_t *row_ind,
+                            uint64_t nnz, uint64_t n_rows, uint64_t n_cols);
 
 /* ---- the step after the path: logp_grad's two sparse products on the resident X ---- */
 

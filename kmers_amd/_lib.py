@@ -101,6 +101,11 @@ def handle():
     lib.kmers_csr_place_rows.argtypes = [C.c_uint64, vp, vp, vp, vp, vp, vp, vp]
     lib.kmers_npz_write_csr.restype = C.c_int
     lib.kmers_npz_write_csr.argtypes = [C.c_char_p, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64]
+    lib.kmers_npz_write_csr_i32.restype = C.c_int
+    lib.kmers_npz_write_csr_i32.argtypes = [C.c_char_p, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64]
+    lib.kmers_fasta_to_kmers_csr_i32.restype = C.c_int
+    lib.kmers_fasta_to_kmers_csr_i32.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_uint64,
+                                                 C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
     lib.kmers_hip_model_create.restype = C.c_int
     lib.kmers_hip_model_create.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp, C.POINTER(vp)]
     lib.kmers_hip_simulate_reads.restype = C.c_int

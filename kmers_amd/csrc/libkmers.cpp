@@ -300,8 +300,9 @@ constexpr uint64_t X_MAX_POS = 0xFFFF0000ull, X_MAX_REC = 0x7FFFFFFFull;  // one
 
 // One store -> CSR in host arrays (data / col_ind hold min(max_size, windows) entries, row_ind 4^K + 1); columns are
 // numbered from the store's first record.
+// idx32: row_ind and col_ind are int32 arrays (the caller narrows anyway: scipy); KMERS_ERR_TOO_LARGE when a value would not fit.
 int build_store(const kmers_store *st, int K, uint64_t max_size, float *data, uint64_t *row_ind, uint64_t *col_ind, uint64_t *nnz,
-                StageClock &clk, Prefault *pre = nullptr) {
+                StageClock &clk, Prefault *pre = nullptr, bool idx32 = false) {
     const uint64_t n_pos = kmers_store_n_pos(st), n_rec = kmers_store_n_rec(st);
     if (n_pos > X_MAX_POS || n_rec > X_MAX_REC) return KMERS_ERR_TOO_LARGE;
     const uint64_t M = 1ull << (2 * K);
@@ -346,28 +347,44 @@ int build_store(const kmers_store *st, int K, uint64_t max_size, float *data, ui
         const uintptr_t a = ((uintptr_t)p + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1), e = ((uintptr_t)p + bytes) & ~(uintptr_t)((2u << 20) - 1);
         if (e > a) (void)madvise((void *)a, e - a, MADV_HUGEPAGE);
     };
+    const size_t isz = idx32 ? 4 : 8;
     if (nz) {
         huge(data, nz * 4);
-        huge(col_ind, nz * 8);
+        huge(col_ind, nz * isz);
     }
-    huge(row_ind, (M + 1) * 8);
+    huge(row_ind, (M + 1) * isz);
     const bool cols_fit = kmers_store_first_rec(st) + n_rec <= 0xFFFFFFFFull;
     const size_t col32_bytes = (size_t)((nz * 4 + 255) / 256 * 256), row32_bytes = (size_t)(M + 1) * 4;
     const bool narrow_cols = cols_fit && nz && col32_bytes <= ws_bytes;
     const bool narrow_rows = (narrow_cols ? col32_bytes : 0) + row32_bytes <= ws_bytes;
+    if (idx32 && (nz > 0x7FFFFFFFull || kmers_store_first_rec(st) + n_rec > 0x7FFFFFFFull))
+        return KMERS_ERR_TOO_LARGE;  // (the 64-bit call takes it)
     uint32_t *d_col32 = d_ws.as<uint32_t>();
     uint32_t *d_row32 = (uint32_t *)((char *)d_ws.p + (narrow_cols ? col32_bytes : 0));
-    if (narrow_cols)
+    DevBuf d_n32;  // idx32 with a workspace too small for the narrowed copies (few positions, many rows): a buffer of their own
+    bool do_cols = narrow_cols, do_rows = narrow_rows;
+    if (idx32 && ((nz && !narrow_cols) || !narrow_rows)) {
+        API_HIP(d_n32.alloc(col32_bytes + row32_bytes));
+        d_col32 = d_n32.as<uint32_t>();
+        d_row32 = (uint32_t *)((char *)d_n32.p + col32_bytes);
+        do_cols = nz != 0, do_rows = true;
+    }
+    if (do_cols)
         if (int e = kk::narrow64(d_col.as<uint64_t>(), d_col32, nz, s)) return e;
-    if (narrow_rows)
+    if (do_rows)
         if (int e = kk::narrow64(d_row.as<uint64_t>(), d_row32, M + 1, s)) return e;
-    if (narrow_rows) {
+    if (idx32) {  // the narrowed arrays as they are (values < 2^31: int32 == uint32)
+        if (int e = d2h_copy(row_ind, d_row32, (M + 1) * 4, s)) return e;
+        if (nz)
+            if (int e = d2h_copy(col_ind, d_col32, nz * 4, s)) return e;
+    } else if (narrow_rows) {
         if (int e = d2h_widen(row_ind, d_row32, M + 1)) return e;
     } else {
         if (int e = d2h_copy(row_ind, d_row.p, (M + 1) * 8, s)) return e;
     }
     if (nz) {
-        if (narrow_cols) {
+        if (idx32) {
+        } else if (narrow_cols) {
             if (int e = d2h_widen(col_ind, d_col32, nz)) return e;
         } else {
             if (int e = d2h_copy(col_ind, d_col.p, nz * 8, s)) return e;
@@ -396,7 +413,7 @@ struct HostCsr {  // one chunk's matrix while the others are built
 };
 
 int build_files(int n_files, const char *fnames[], int K, int L, int mode, float *data, uint64_t *row_ind, uint64_t *col_ind,
-                uint64_t max_size, uint64_t *nnz, int *n_cols) {
+                uint64_t max_size, uint64_t *nnz, int *n_cols, bool idx32 = false) {
     if (K < 1 || K > 16 || !row_ind || !nnz || !n_cols || n_files < 0 || (max_size && (!data || !col_ind)))
         return KMERS_ERR_BAD_ARG;
     StageClock clk;
@@ -411,8 +428,8 @@ int build_files(int n_files, const char *fnames[], int K, int L, int mode, float
     }
     const uint64_t pre_n = std::min(max_size, file_bytes);
     Prefault pre;
-    pre.add(row_ind, (size_t)(M + 1) * 8);
-    pre.add(col_ind, (size_t)pre_n * 8);
+    pre.add(row_ind, (size_t)(M + 1) * (idx32 ? 4 : 8));
+    pre.add(col_ind, (size_t)pre_n * (idx32 ? 4 : 8));
     pre.add(data, (size_t)pre_n * 4);
     pre.start(prefault_threads());
     {
@@ -428,12 +445,13 @@ int build_files(int n_files, const char *fnames[], int K, int L, int mode, float
             if (v < X_MAX_POS) chunk_pos = v;
         if (n_pos <= chunk_pos && n_rec_total <= X_MAX_REC) {
             uint64_t nz = 0;
-            if (int rc = build_store(g.s, K, max_size, data, row_ind, col_ind, &nz, clk, &pre)) return rc;
+            if (int rc = build_store(g.s, K, max_size, data, row_ind, col_ind, &nz, clk, &pre, idx32)) return rc;
             *nnz = nz;
             *n_cols = (int)n_rec_total;
             return KMERS_OK;
         }
         pre.finish();
+        if (idx32) return KMERS_ERR_TOO_LARGE;  // (ranges are merged from 64-bit parts: the 64-bit call takes it)
         // more positions than one device call indexes: contiguous record ranges (the ingest's shards, balanced by
         // positions), one matrix each, interleaved row by row at the end (columns ascend from range to range)
         const uint64_t *rs = kmers_store_rec_start(g.s);
@@ -549,6 +567,14 @@ int fasta_to_kmers_csr_cat_subseq(int n_files, const char *fnames[], int K, int 
                                   uint64_t *col_ind, uint64_t max_size, uint64_t *nnz, int *n_cols) {
     return report(build_files(n_files, fnames, K, L, KMERS_MODE_X_CAT, data, row_ind, col_ind, max_size, nnz, n_cols),
                   "fasta_to_kmers_csr_cat_subseq");
+}
+
+int kmers_fasta_to_kmers_csr_i32(int n_files, const char *fnames[], int K, int L, int concatenate_subseq, float *data,
+                                 int32_t *row_ind, int32_t *col_ind, uint64_t max_size, uint64_t *nnz, int *n_cols) {
+    // (no report(): KMERS_ERR_TOO_LARGE is this call's way of saying "use the 64-bit one", not a failure to announce)
+    const int rc = build_files(n_files, fnames, K, L, concatenate_subseq ? KMERS_MODE_X_CAT : KMERS_MODE_X, data,
+                               (uint64_t *)row_ind, (uint64_t *)col_ind, max_size, nnz, n_cols, true);
+    return rc == KMERS_ERR_TOO_LARGE ? rc : report(rc, "kmers_fasta_to_kmers_csr_i32");
 }
 
 // ---- device-resident stages ----------------------------------------------------------------------------

@@ -251,3 +251,37 @@ extern "C" int kmers_npz_write_csr(const char *path, const float *data, const ui
     }
     return KMERS_OK;
 }
+
+extern "C" int kmers_npz_write_csr_i32(const char *path, const float *data, const int32_t *col_ind, const int32_t *row_ind,
+                                       uint64_t nnz, uint64_t n_rows, uint64_t n_cols) {
+    if (!path || !row_ind || (nnz && (!data || !col_ind))) return KMERS_ERR_BAD_ARG;
+    if (std::max(std::max(n_rows, n_cols), nnz) > 0x7FFFFFFFull) return KMERS_ERR_TOO_LARGE;  // scipy would store int64
+    Writer w;
+    w.f = fopen(path, "wb");
+    if (!w.f) return KMERS_ERR_OPEN;
+    auto as_is = [](const void *src, size_t elem) {
+        return [src, elem](unsigned char *, uint64_t at, uint64_t) { return reinterpret_cast<const unsigned char *>(src) + at * elem; };
+    };
+    array_member(w, "indices.npy", "<i4", nnz, 4, as_is(col_ind, 4));
+    array_member(w, "indptr.npy", "<i4", n_rows + 1, 4, as_is(row_ind, 4));
+    {
+        const std::string h = npy_header("|S3", "()") + "csr";
+        w.begin_member("format.npy", h.size());
+        w.write(h.data(), h.size());
+        w.end_member((uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)h.data(), (uInt)h.size()));
+    }
+    {
+        const int64_t shape[2] = {(int64_t)n_rows, (int64_t)n_cols};
+        array_member(w, "shape.npy", "<i8", 2, 8, [&](unsigned char *, uint64_t, uint64_t) {
+            return reinterpret_cast<const unsigned char *>(shape);
+        });
+    }
+    array_member(w, "data.npy", "<f4", nnz, 4, as_is(data, 4));
+    w.finish();
+    if (fclose(w.f) != 0) w.ok = false;
+    if (!w.ok) {
+        remove(path);
+        return KMERS_ERR_OPEN;
+    }
+    return KMERS_OK;
+}

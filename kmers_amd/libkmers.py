@@ -62,6 +62,32 @@ def fastq_gz_count_kmers(fastq_files, K):
     return counts
 
 
+def fasta_to_kmers_csr_i32(fasta_files, K, max_nz=0, L=0, concatenate_subseq=False):
+    """fasta_to_kmers_csr with int32 row_ind / col_ind (kmers_fasta_to_kmers_csr_i32, include/kmers_hip.h): what
+    transcriptome_to_x hands to scipy, which would narrow uint64 indices to int32 itself.  None when the indices do not
+    fit int32 or the input is above one device call (the caller then takes fasta_to_kmers_csr).  No counterpart in the
+    reference."""
+    fasta_files = _as_list(fasta_files)
+    if max_nz == 0:
+        max_nz = _get_total_size(fasta_files)
+    M = 4 ** K
+    if max(M + 1, max_nz) > 0x7FFFFFFF:
+        return None
+    data = np.zeros(max_nz, dtype=np.float32)
+    col_ind = np.zeros(max_nz, dtype=np.int32)
+    row_ind = np.zeros(M + 1, dtype=np.int32)
+    pos = c_uint64(0)
+    n_cols = c_int(0)
+    failed = _lib.handle().kmers_fasta_to_kmers_csr_i32(len(fasta_files), _lib.cfiles(fasta_files), K, L, int(bool(concatenate_subseq)),
+                                                        data.ctypes.data, row_ind.ctypes.data, col_ind.ctypes.data, max_nz,
+                                                        byref(pos), byref(n_cols))
+    if failed == -13:       # KMERS_ERR_TOO_LARGE: not an error here
+        return None
+    _raise(failed, "Failed to open FASTA file")
+    pos = pos.value
+    return data[0:pos], row_ind, col_ind[0:pos], n_cols.value
+
+
 def fasta_to_kmers_csr(fasta_files, K, max_nz=0, L=0, concatenate_subseq=False):
     """CSR arrays of X (reference kmerexpr/libkmers.py:130-184): (data, row_ind, col_ind, n_cols).
 

@@ -4,7 +4,7 @@ import numpy as np
 from scipy.sparse import csr_matrix, load_npz
 
 from . import _lib
-from .libkmers import fasta_to_kmers_csr
+from .libkmers import fasta_to_kmers_csr, fasta_to_kmers_csr_i32
 
 
 def save_x_npz(x_file, data, row_ind, col_ind, n_rows, n_cols):
@@ -15,11 +15,15 @@ def save_x_npz(x_file, data, row_ind, col_ind, n_rows, n_cols):
     if not x_file.endswith(".npz"):
         x_file += ".npz"           # what scipy's save_npz does
     data = np.ascontiguousarray(data, dtype=np.float32)
-    row_ind = np.ascontiguousarray(row_ind, dtype=np.uint64)
-    col_ind = np.ascontiguousarray(col_ind, dtype=np.uint64)
+    if row_ind.dtype == np.int32 and col_ind.dtype == np.int32:      # the arrays of fasta_to_kmers_csr_i32, as they are
+        row_ind, col_ind = np.ascontiguousarray(row_ind), np.ascontiguousarray(col_ind)
+        write = _lib.handle().kmers_npz_write_csr_i32
+    else:
+        row_ind = np.ascontiguousarray(row_ind, dtype=np.uint64)
+        col_ind = np.ascontiguousarray(col_ind, dtype=np.uint64)
+        write = _lib.handle().kmers_npz_write_csr
     assert row_ind.shape[0] == n_rows + 1 and col_ind.shape[0] == data.shape[0]
-    rc = _lib.handle().kmers_npz_write_csr(x_file.encode("UTF-8"), data.ctypes.data, col_ind.ctypes.data,
-                                           row_ind.ctypes.data, data.shape[0], n_rows, n_cols)
+    rc = write(x_file.encode("UTF-8"), data.ctypes.data, col_ind.ctypes.data, row_ind.ctypes.data, data.shape[0], n_rows, n_cols)
     if rc == -1:
         raise OSError(f"cannot write {x_file}")
     _lib.check(rc, "kmers_npz_write_csr")
@@ -39,8 +43,12 @@ def transcriptome_to_x(K, fasta_files, x_file="", L=0, max_nz=0, float_t=np.floa
     if float_t != np.float32:
         raise ValueError("Only float_t=np.float32 currently supported for fast reader")
     M = 4 ** K
-    data, row_ind, col_ind, n_cols = fasta_to_kmers_csr(fasta_files, K, max_nz, L=L,
-                                                        concatenate_subseq=concatenate_subseq)
+    # scipy keeps int32 indices whenever they fit: ask the library for them (they leave the device as 32-bit values
+    # anyway) instead of letting csr_matrix() narrow 3 GB of uint64 on one core; the uint64 call is the fallback
+    res = fasta_to_kmers_csr_i32(fasta_files, K, max_nz, L=L, concatenate_subseq=concatenate_subseq)
+    if res is None:
+        res = fasta_to_kmers_csr(fasta_files, K, max_nz, L=L, concatenate_subseq=concatenate_subseq)
+    data, row_ind, col_ind, n_cols = res
     if x_file:
         save_x_npz(x_file, data, row_ind, col_ind, M, n_cols)
     return csr_matrix((data, col_ind, row_ind), shape=(M, n_cols), dtype=float_t)

@@ -177,3 +177,33 @@ def test_stage_record_of_the_file_level_calls(product, tmp_path):
     st = _lib.last_call_stages()
     assert list(st) == ["host ingest", "H2D + device buffers", "histogram (GPU, enqueue)", "counts += (D2H)"]
     assert all(v >= 0.0 for v in st.values())
+
+
+@pytest.mark.parametrize("K,L,cat", [(8, 0, False), (12, 0, False), (6, 1500, True)])
+def test_transcriptome_to_x_takes_int32_indices_from_the_library(product, tmp_path, K, L, cat):
+    """transcriptome_to_x asks for int32 indices (kmers_fasta_to_kmers_csr_i32) instead of letting scipy narrow the ABI's
+    uint64 arrays: the matrix and the .npz must be what the uint64 route gives (reference
+    kmerexpr/transcriptome_reader.py:33-39: csr_matrix of the ABI arrays, save_npz uncompressed)."""
+    from scipy.sparse import csr_matrix, save_npz
+    from kmers_amd import synth
+    iso, iso2 = str(tmp_path / "t.fsa"), str(tmp_path / "u.fsa")
+    synth.synth_transcriptome(iso, n_records=300, total_bases=500_000, seed=4)
+    synth.synth_transcriptome(iso2, n_records=20, total_bases=30_000, seed=5)
+    files = [iso, iso2]
+    res = libkmers.fasta_to_kmers_csr_i32(files, K, L=L, concatenate_subseq=cat)
+    assert res is not None and res[1].dtype == np.int32 and res[2].dtype == np.int32
+    rc, data, row, col, n_cols = product.x(files, K, L, cat)
+    assert rc == 0 and res[3] == n_cols
+    assert np.array_equal(res[0].view(np.uint32), data.view(np.uint32))
+    assert np.array_equal(res[1], row.astype(np.int32)) and np.array_equal(res[2], col.astype(np.int32))
+    ours = str(tmp_path / "x.npz")
+    x = tr.transcriptome_to_x(K, files, ours, L=L, concatenate_subseq=cat)
+    want = csr_matrix((data, col, row), shape=(4 ** K, n_cols), dtype=np.float32)
+    assert x.indices.dtype == want.indices.dtype == np.int32 and x.shape == want.shape
+    assert np.array_equal(x.indptr, want.indptr) and np.array_equal(x.indices, want.indices)
+    assert np.array_equal(x.data.view(np.uint32), want.data.view(np.uint32))
+    theirs = str(tmp_path / "theirs.npz")
+    save_npz(theirs, want, compressed=False)
+    a, b = np.load(ours), np.load(theirs)
+    for k in b.files:
+        assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), k

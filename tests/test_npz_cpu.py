@@ -82,3 +82,18 @@ def test_npz_many_chunks_and_wide_indices(tmp_path):
     want = csr_matrix((data[:1000], col_ind[-1000:], np.minimum(row_ind, 1000)), shape=(M, n_cols))
     assert want.indices.dtype == np.int64                # scipy's own choice for this shape
     assert (got != want).nnz == 0
+
+
+@pytest.mark.parametrize("case", X_CASES[1::5], ids=lambda c: c["name"])
+def test_npz_from_int32_indices_is_the_same_file(tmp_path, case):
+    """kmers_npz_write_csr_i32 (the arrays of kmers_fasta_to_kmers_csr_i32, which transcriptome_to_x uses) writes the
+    file kmers_npz_write_csr writes from the uint64 arrays, byte for byte; and it refuses what scipy would store as int64."""
+    from kmers_amd import _lib
+    data, row_ind, col_ind, M, n_cols = _golden_csr(case)
+    a, b = str(tmp_path / "a.npz"), str(tmp_path / "b.npz")
+    tr.save_x_npz(a, data, row_ind, col_ind, M, n_cols)
+    tr.save_x_npz(b, data, row_ind.astype(np.int32), col_ind.astype(np.int32), M, n_cols)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    z = np.zeros(2, np.int32)
+    rc = _lib.handle().kmers_npz_write_csr_i32(str(tmp_path / "c.npz").encode(), None, None, z.ctypes.data, 0, 1, 2 ** 31)
+    assert rc == -13 and not os.path.exists(tmp_path / "c.npz")
