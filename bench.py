@@ -368,9 +368,20 @@ def e2e_record(args, K, kind_x):
         times.append(time.perf_counter() - t0)
         if times[-1] == min(times):
             stages = _lib.last_call_stages()
-    return {"call": call, "input": what, "wall_s": round(min(times), 4), "calls": len(times),
-            "stages_ms": {k: round(v, 2) for k, v in (stages or {}).items()},
-            "host_threads": host_threads()}
+    rec = {"call": call, "input": what, "wall_s": round(min(times), 4), "calls": len(times),
+           "stages_ms": {k: round(v, 2) for k, v in (stages or {}).items()},
+           "host_threads": host_threads()}
+    if kind_x:       # the call the reference's users make (kmerexpr/transcriptome_reader.py:19-41): the arrays + scipy's csr_matrix
+        from kmers_amd import transcriptome_reader as tr
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            x = tr.transcriptome_to_x(K, path)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            del x
+        rec["transcriptome_to_x_s"] = round(best, 4)
+    return rec
 
 
 # ------------------------------------------------------------------------------------------------ the workloads
