@@ -33,6 +33,34 @@ def length_adjustment_inverse(theta, lengths):
     return psi / psi.sum()
 
 
+def _choice_with_p(T, N, p):
+    """np.random.choice(T, size=N, replace=True, p=p) of numpy's LEGACY generator, whose algorithm is frozen
+    (numpy/random/mtrand.pyx, RandomState.choice): cdf = p.cumsum(); cdf /= cdf[-1]; u = random_sample(N);
+    idx = cdf.searchsorted(u, side='right').  The same calls on the same stream -- only the N binary searches, nine
+    tenths of its time, run on all host threads (searchsorted releases the GIL).  The first few thousand results are
+    checked against numpy's own choice() on a copy of the generator state, so a numpy that ever did it differently would
+    be noticed here and not in y."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    n_check = min(N, 4096)
+    state = np.random.get_state()
+    check = np.random.choice(T, size=n_check, replace=True, p=p)
+    np.random.set_state(state)
+    cdf = p.cumsum()
+    cdf /= cdf[-1]
+    u = np.random.random_sample(N)
+    idx = np.empty(N, np.int64)
+    n_thr = max(1, min(int(os.environ.get("KMER_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1), 64))
+    step = max(1 << 16, -(-N // n_thr))
+    with ThreadPoolExecutor(n_thr) as ex:
+        list(ex.map(lambda lo: idx.__setitem__(slice(lo, lo + step), cdf.searchsorted(u[lo:lo + step], side="right")),
+                    range(0, N, step)))
+    if not np.array_equal(idx[:n_check], check):
+        raise RuntimeError("numpy's legacy choice() no longer matches its restatement here: refusing to guess")
+    return idx
+
+
 def sample_reads(rec_lengths, N, L, alpha):
     """The reference's random choices for isoforms of the given lengths (all >= L): returns
     dict(psi, theta_true, theta_sampled, lengths, iso_sampled int64[N], starts uint32[N])."""
@@ -43,7 +71,7 @@ def sample_reads(rec_lengths, N, L, alpha):
     assert T > 0 and lengths.min() >= 1
     psi = np.random.dirichlet(alpha * np.ones(T))             # :95-96
     theta_true = length_adjustment(psi, lengths)              # :101
-    iso_sampled = np.random.choice(T, size=N, replace=True, p=theta_true)    # :105
+    iso_sampled = _choice_with_p(T, N, theta_true)            # :105 np.random.choice(T, size=N, replace=True, p=theta_true)
     theta_sampled = np.bincount(iso_sampled, minlength=T) / N                # :107-108
     # :116, N times: start = np.random.choice(len(seq) - L + 1), replayed over raw 32-bit outputs of the same stream
     n_choices = np.ascontiguousarray(lengths[iso_sampled], dtype=np.uint32)
