@@ -444,6 +444,9 @@ __global__ __launch_bounds__(YL_NT) void k_count_y_lds(BasesArgs a, int32_t *cou
 #ifndef HW_SUB
 #define HW_SUB 4
 #endif
+#ifndef HH_SUB
+#define HH_SUB 4
+#endif
 
 #ifndef YS32_BLOCKS
 #define YS32_BLOCKS 256
@@ -2122,14 +2125,17 @@ __global__ __launch_bounds__(NT) void k_heads_hist(const uint32_t *ent, const ui
     __shared__ uint32_t s_reg[RADIX + 1], s_ts[RADIX + 1];
     __shared__ uint32_t T[NW][RADIX];
     __shared__ u64 wmask[NW][RADIX];
-    __shared__ uint32_t hist[2][RADIX];
+    // (HH_SUB copies of the tile's table by lane, as in k_hist_words_y)
+    constexpr uint32_t HSUBW = HH_SUB * (RADIX + 1);
+    __shared__ uint32_t hist[2][HSUBW];
     const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
     for (uint32_t i = tid; i <= RADIX; i += NT) {
         s_reg[i] = regions[i];
         s_ts[i] = tstart[i];
     }
     for (uint32_t i = tid; i < NW * RADIX; i += NT) (&wmask[0][0])[i] = 0ull;
-    for (uint32_t i = tid; i < 2 * RADIX; i += NT) (&hist[0][0])[i] = 0u;
+    for (uint32_t i = tid; i < 2 * HSUBW; i += NT) (&hist[0][0])[i] = 0u;
+    const uint32_t hsub = (lane % HH_SUB) * (RADIX + 1);
     lds_sync();
     const uint32_t n_ft = s_ts[RADIX];
     const uint32_t per = (rows + gridDim.x - 1) / gridDim.x;
@@ -2151,7 +2157,7 @@ __global__ __launch_bounds__(NT) void k_heads_hist(const uint32_t *ent, const ui
     };
     if (t0 < t1) load_tile(t0);
     for (uint32_t tile = t0; tile < t1; ++tile) {
-        uint32_t *const hc = hist[(tile - t0) & 1u], *const hn = hist[((tile - t0) & 1u) ^ 1u];
+        uint32_t *const hr = hist[(tile - t0) & 1u], *const hc = hr + hsub;
         if (tile >= n_ft) {  // rows past the last tile: zeros (the scan runs over all `rows`)
             if (tid < RADIX) tilehist[(uint64_t)tile * RADIX + tid] = 0u;
             continue;
@@ -2205,10 +2211,18 @@ __global__ __launch_bounds__(NT) void k_heads_hist(const uint32_t *ent, const ui
             asm volatile("" ::: "memory");
         }
         if (tile + 1 < t1) load_tile(tile + 1);
-        if (tid < RADIX) hn[tid] = 0u;  // the other table, for the next tile
         lds_sync();
-        // (no second barrier: the next tile's atomics go to hn; hc[tid] is zeroed a tile later by the thread that reads it here)
-        if (tid < RADIX) tilehist[(uint64_t)tile * RADIX + tid] = hc[tid];
+        // (no second barrier: the next tile's atomics go to the other table; these words are cleared here, by the thread
+        // that reads them, for the tile after next)
+        if (tid < RADIX) {
+            uint32_t sum = 0;
+#pragma unroll
+            for (uint32_t c = 0; c < HH_SUB; ++c) {
+                sum += hr[c * (RADIX + 1) + tid];
+                hr[c * (RADIX + 1) + tid] = 0u;
+            }
+            tilehist[(uint64_t)tile * RADIX + tid] = sum;
+        }
     }
 }
 
