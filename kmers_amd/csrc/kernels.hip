@@ -632,8 +632,11 @@ template <class ET, int BNT, int WPT>
 __global__ __launch_bounds__(BNT) void k_yscatter(BasesArgs a, const uint32_t *tilebase, const uint32_t *regions, uint64_t n_words8,
                                                   uint32_t n_tiles, ET *out) {
     constexpr int BNW = BNT / 64, BTILE = BNT * WPT * 16;  // WPT packed words per thread
-    __shared__ __attribute__((aligned(16))) ET sent[BTILE];
-    __shared__ uint8_t saux[BTILE];
+    // staged as 32-bit words, the entry with its digit in bits 16..23 (free in both forms: a 2-byte payload, or
+    // (key byte << 24 | at most 16 low bits)): ONE LDS store per window where rounds 1-2 kept a digit byte beside every
+    // entry, and the write-out finds the entry's global offset from the word it reads anyway (y12: 10.0 -> 9.6 ms per
+    // step; deriving the digit from the digit ENDS in a per-wave walk instead was built too: 10.6 - 13.8 ms)
+    __shared__ __attribute__((aligned(16))) uint32_t sent[BTILE];
     __shared__ __attribute__((aligned(16))) uint32_t cnt[2][RADIX], gadj[2][RADIX];
     __shared__ uint32_t s_count[2];
     const uint32_t tid = threadIdx.x, w = tid >> 6, lane = lane_id();
@@ -693,12 +696,9 @@ __global__ __launch_bounds__(BNT) void k_yscatter(BasesArgs a, const uint32_t *t
                     const uint32_t d = (top >> dshift) & 255u, key = top >> ksh;
                     const uint32_t slot = atomicAdd(&cnt[buf][d], 1u);
                     if constexpr (sizeof(ET) == 2)
-                        sent[slot] = (ET)(key & low_mask);
+                        sent[slot] = (key & low_mask) | (d << 16);
                     else
-                        sent[slot] = (ET)((((key >> a.low_bits) >> 8) << 24) | (key & low_mask));
-#if !defined(YS_ABL) || YS_ABL < 2
-                    saux[slot] = (uint8_t)d;
-#endif
+                        sent[slot] = (((key >> a.low_bits) >> 8) << 24) | (d << 16) | (key & low_mask);
                 }
             }
         }
@@ -708,10 +708,13 @@ __global__ __launch_bounds__(BNT) void k_yscatter(BasesArgs a, const uint32_t *t
             row_lo = row_hi;
         }
         const uint32_t tile_count = s_count[buf];
-#if !defined(YS_ABL)   // (YS_ABL: timing-only builds without the write-out, 2: also without the digit bytes)
-        for (uint32_t i = tid; i < tile_count; i += BNT) out[gadj[buf][saux[i]] + i] = sent[i];
+#if !defined(YS_ABL)  // (YS_ABL: timing-only builds without the write-out)
+        for (uint32_t i = tid; i < tile_count; i += BNT) {
+            const uint32_t v = sent[i];
+            out[gadj[buf][(v >> 16) & 255u] + i] = (ET)(v & 0xFF00FFFFu);
+        }
 #else
-        if (tile_count == 0xFFFFFFFFu) out[tid] = sent[tid] + saux[tid];
+        if (tile_count == 0xFFFFFFFFu) out[tid] = (ET)sent[tid];
 #endif
         lds_sync();
     }
