@@ -288,3 +288,24 @@ def test_x14_in_three_passes_equals_four(product, oracle, syn, knob):
     kmtest.assert_x_equal(product.x(files, 14), want)
     kmtest.assert_x_equal(product.x(files, 13), oracle.x(files, 13))
     kmtest.assert_x_equal(product.x(files, 9), oracle.x(files, 9))
+
+
+@pytest.mark.parametrize("K", [9, 10, 12, 13, 14])
+def test_y_several_hot_kmers_in_one_slice(oracle, tmp_path, K):
+    """k_count_y_sorted keeps ONE hot entry value per lane in a register (the poly-A case) and changes it when a load
+    with an equal pair no longer holds it: reads that mix poly-A, AAAA...C, dinucleotide repeats (two alternating
+    k-mers), poly-T and random sequence put several hot k-mers into the same and into different slices, in runs of every
+    length, so the hand-over between hot values and the final flush are exercised."""
+    rng = np.random.default_rng(1000 + K)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    p = tmp_path / "hots.fsa"
+    kinds = [lambda n: b"A" * n, lambda n: (b"A" * (n - 1)) + b"C", lambda n: (b"AC" * n)[:n], lambda n: b"T" * n,
+             lambda n: (b"AAAC" * n)[:n], lambda n: bytes(rng.choice(acgt, n)), lambda n: (b"A" * (n // 2)) + bytes(rng.choice(acgt, n - n // 2))]
+    with open(p, "wb") as f:
+        for i in range(30000):
+            n = int(rng.integers(K, 160))
+            f.write(b">r%d\n%s\n" % (i, kinds[int(rng.integers(0, len(kinds)))](n)))
+    rc, want = oracle.y([str(p)], K)
+    from kmers_amd.store import MODE_Y_FASTA, Store
+    got = Store(str(p), MODE_Y_FASTA).to_device().count_y(K).cpu().numpy()
+    assert rc == 0 and int(want[0]) > 100000 and np.array_equal(got, want)
